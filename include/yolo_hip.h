@@ -1,0 +1,164 @@
+/*
+ * yolo_hip.h -- C ABI of libyolo_hip.so: the gfx950 (MI355X) implementation of the YOLOv3
+ * inference hot path of shiboyang/YOLO.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point below replaces the
+ * torch / detectron2 / torchvision call chain cited next to it (paths relative to the reference
+ * checkout).  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     never synchronises and never allocates: the caller owns all buffers incl. the workspace;
+ *   - return value 0 = ok, negative = error (YOLO_E_*); yolo_last_error() gives the message of the
+ *     calling thread's last failure;
+ *   - activations are NHWC ("pixel-major") with an optional zero halo of `halo` pixels on each
+ *     spatial side, and may be a channel slice of a wider buffer:
+ *       element (n, y, x, c) of a view {ptr, H, W, halo, ch_total, ch_offset} lives at
+ *       ptr[((n*(H+2*halo) + y+halo)*(W+2*halo) + x+halo)*ch_total + ch_offset + c].
+ *     Kernels only ever write the interior, so a halo zeroed once stays zero.
+ */
+#ifndef YOLO_HIP_H
+#define YOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOLO_OK 0
+#define YOLO_E_ARG (-1)      /* invalid argument / unsupported shape */
+#define YOLO_E_WORKSPACE (-2) /* workspace too small */
+#define YOLO_E_HIP (-3)      /* a HIP runtime call failed */
+
+#define YOLO_F32 0
+#define YOLO_BF16 1
+
+/* NMS modes, see yolo_batched_nms */
+#define YOLO_NMS_PER_CLASS 0   /* torchvision _batched_nms_vanilla */
+#define YOLO_NMS_COORD_TRICK 1 /* torchvision _batched_nms_coordinate_trick */
+#define YOLO_NMS_AUTO 2        /* torchvision batched_nms branch rule, per image */
+
+const char* yolo_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int yolo_abi_version(void);
+
+/* A strided NHWC view (see the layout rule above). */
+typedef struct yolo_view {
+    void* ptr;
+    int H, W;      /* logical spatial size */
+    int halo;      /* zero border in the buffer, pixels per side */
+    int ch_total;  /* channels per pixel in the buffer */
+    int ch_offset; /* first channel of this view */
+} yolo_view;
+
+/*
+ * Fused convolution: y = act(conv(x, w) + bias) [+ residual], optionally written 2x nearest-
+ * upsampled.  Replaces detectron2 Conv2d.forward (F.conv2d + eval BatchNorm, folded by the caller
+ * into w/bias) + F.leaky_relu at yolo/modeling/backbone/darknet.py:58-59,115-116,119-123 and
+ * fpn.py:34-35,68-69,97-99; the `out += residual` of darknet.py:118,125 (added AFTER the activation);
+ * nn.Upsample(2, nearest) of fpn.py:36; and, through y.ch_offset, the torch.cat of fpn.py:179.
+ *
+ *   x        input view, N images, Cin channels; x.halo >= pad is required (zero padding comes from
+ *            the halo), Cin % 8 == 0 for bf16 (Cin % 4 for f32); Cin == 32 or Cin % 64 == 0 (bf16),
+ *            Cin % 32 == 0 (f32)
+ *   w_packed [Cout_pad][k][k][Cin] in `dtype`, Cout_pad = Cout rounded up to 128, rows >= Cout zero
+ *   bias     [Cout_pad] f32
+ *   residual NULL, or a view with y's geometry (its own ptr / ch_total / ch_offset / halo)
+ *   y        output view with H, W = conv output size (2x that when upsample2x)
+ *   k in {1,3}; stride in {1,2}; pad = (k-1)/2
+ *   leaky_slope: negative-side slope; 1.0f = linear (no activation)
+ *   dtype    element type of x, w_packed, residual (YOLO_F32 / YOLO_BF16); accumulation is f32
+ *   y_dtype  element type of y
+ */
+int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,
+                    const yolo_view* residual, const yolo_view* y,
+                    int N, int Cin, int Cout, int k, int stride,
+                    float leaky_slope, int upsample2x, int dtype, int y_dtype, void* stream);
+
+/* Rows of the packed weight buffer for Cout output channels (Cout rounded up to the channel tile). */
+int yolo_conv_cout_pad(int Cout);
+
+/*
+ * First layer: pixel normalisation + zero padding + 3x3/s1 stem conv + bias + LeakyReLU.
+ * Replaces DenseDetector.preprocess_image (driven by configs/yolov3.yaml:5-6 and fpn.py:161-163)
+ * and BasicStem.forward (darknet.py:57-60).
+ *   img      N images, planar CHW (3,Hs,Ws) each, contiguous: float32 (img_dtype 0) or uint8 (1),
+ *            values 0..255, channel order already the model's (tools/inference.py:38-39)
+ *   Hs, Ws   stored image size; pixels outside it (up to y.H, y.W) are zero AFTER normalisation
+ *   mean_host, std_host  host arrays [3]: (v - mean[c]) / std[c], as the reference computes it
+ *   w        [3][3][3][Cout] (kh,kw,cin,cout) f32, BN folded; bias [Cout] f32; Cout == 32
+ *   y        output view (H, W multiples of 32 by the reference's size_divisibility)
+ */
+int yolo_stem_fwd(const void* img, int img_dtype, int N, int Hs, int Ws,
+                  const float* mean_host, const float* std_host,
+                  const float* w, const float* bias, const yolo_view* y, int Cout,
+                  float leaky_slope, int y_dtype, void* stream);
+
+/* Nearest-neighbour 2x upsample of an NHWC view into another (channel slice of a) view.
+ * Replaces nn.Upsample(scale_factor=2, mode="nearest") + torch.cat at fpn.py:31,36,179 for
+ * callers that do not use yolo_conv2d_fwd's fused form.  C % 8 == 0 (bf16) / % 4 (f32). */
+int yolo_upsample2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
+
+/*
+ * Head activation + anchor decode + two-stage score filter + order-preserving compaction.
+ * Replaces YoloV3Head.forward (yolo/modeling/meta_arch/yolo.py:392-420), _transpose_dense_predictions
+ * (:276-278), the anchor generator call (:279, yolo/modeling/anchor_generator.py:18-40) and
+ * _decode_multi_level_predictions / _decode_per_level_predictions (:309-383) with
+ * Box2BoxTransform.apply_deltas (yolo/modeling/box_regression.py:44-64), for all images at once.
+ *
+ *   head[l]      raw head tensor of level l (0 = finest stride), NHWC view with A*(5+C) channels,
+ *                channel = a*(5+C) + {tx,ty,tw,th,obj,cls0..}
+ *   stride_host  [L] strides; anchors_wh_host [L][A][2] anchor (w,h) in input pixels
+ *   thr          strict '>' threshold used for BOTH the objectness and the class*objectness filter
+ *   outputs (candidate order = image, level, y, x, anchor, class -- the reference's order):
+ *     boxes [cap][4] f32 xyxy, scores [cap] f32, classes [cap] i32,
+ *     img_offsets [N+1] i32: candidates of image n are [img_offsets[n], img_offsets[n+1]);
+ *                img_offsets[N] is the TRUE total even if it exceeds cap (writes beyond cap are
+ *                dropped, so compare it with cap to detect overflow)
+ *   workspace    yolo_decode_workspace_bytes(...) bytes
+ */
+int yolo_decode(const yolo_view* head, int L, const int* stride_host, const float* anchors_wh_host,
+                int N, int A, int C, float thr, int head_dtype,
+                float* boxes, float* scores, int* classes, int* img_offsets, int cap,
+                void* workspace, size_t ws_bytes, void* stream);
+size_t yolo_decode_workspace_bytes(const yolo_view* head, int L, int N);
+
+/*
+ * Batched per-class NMS over all images.  Replaces batched_nms(boxes, scores, classes, thr) at
+ * yolo/modeling/meta_arch/yolo.py:305 (detectron2.layers.batched_nms -> torchvision batched_nms ->
+ * torchvision::nms) and the keep[:max_detections] truncation at :307.
+ *
+ *   boxes/scores/classes  M candidates grouped by image through img_offsets [N+1] (device)
+ *   M_host        number of candidates (host value; = img_offsets[N])
+ *   iou_thr       suppression when (double)(float iou) > iou_thr, strict
+ *   mode          YOLO_NMS_*; AUTO applies torchvision's rule per image with `auto_numel_limit`
+ *                 (4000 = what the reference does on CPU, 20000 = on a GPU): coordinate trick when
+ *                 4*M_img <= limit
+ *   top_k         > 0: return only the first top_k kept per image (yolo.py:307); 0: all
+ *   num_classes   class ids are in [0, num_classes)
+ *   keep          [N][keep_stride] i32: per image, indices RELATIVE to the image's first candidate,
+ *                 in descending score order (ties: ascending index)
+ *   n_keep        [N] i32 number of valid entries per image
+ */
+int yolo_batched_nms(const float* boxes, const float* scores, const int* classes,
+                     const int* img_offsets, int N, int M_host, double iou_thr, int mode,
+                     int auto_numel_limit, int top_k, int num_classes, int* keep, int keep_stride,
+                     int* n_keep, void* workspace, size_t ws_bytes, void* stream);
+size_t yolo_nms_workspace_bytes(int N, int M);
+
+/*
+ * Gather kept detections and map them to the output frame.  Replaces pred[keep[:100]] (yolo.py:307)
+ * and detectron2's detector_postprocess (scale to the requested size, clip, drop empty boxes).
+ *   in_hw  [N][2] i32 (device) network-input image size (h,w) before padding; out_hw [N][2] requested size
+ *   det         [N][keep_stride][6] f32: x0,y0,x1,y1,score,class ; n_det [N] i32
+ */
+int yolo_gather_detections(const float* boxes, const float* scores, const int* classes,
+                           const int* img_offsets, const int* keep, int keep_stride, const int* n_keep,
+                           int N, const int* in_hw, const int* out_hw,
+                           float* det, int* n_det, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H */

@@ -1,0 +1,193 @@
+"""GPU parity of yolo_decode / yolo_batched_nms / yolo_gather_detections against the CPU oracle
+(oracle/yolo_ref.py restating yolo/modeling/meta_arch/yolo.py:266-383 and box_regression.py:44-64;
+oracle/nms_ref.c restating torchvision's batched_nms as called at yolo.py:305).
+
+Decode is floating point: candidates must agree except where a score sits within 1e-5 of the
+threshold; boxes/scores within 1e-4 relative (torch CPU vs GPU exp differ by ulps).
+NMS is integer output: kept indices bit-exact given identical fp32 boxes and scores.
+"""
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _heads_to_views(heads, dtype, cuda, ops, ch_pad=256):
+    views = []
+    for h in heads:
+        N, AK, gh, gw = h.shape
+        v = ops.alloc_view(N, gh, gw, max(ch_pad, (AK + 7) // 8 * 8), 0, dtype, cuda)
+        v.interior()[..., :AK].copy_(h.permute(0, 2, 3, 1).to(cuda))
+        views.append(ops.View(v.buf, gh, gw, 0, AK, 0))
+    return views
+
+
+def _check_decode(cuda, N, C, grids, thr, dtype, seed, obj_bias=-2.0, ch_pad=256):
+    from oracle import yolo_ref as R
+    from yolo_amd import ops
+    heads = util.random_heads(N, C, grids, seed, obj_bias)
+    if dtype == torch.bfloat16:
+        heads = [h.bfloat16().float() for h in heads]
+    ref = R.decode_batch(heads, C, thr)
+    views = _heads_to_views(heads, dtype, cuda, ops, ch_pad)
+    cap = sum(r[0].shape[0] for r in ref) + 4096
+    anchors = [[tuple(map(float, R.cell_anchors()[l][a, 2:] * 2)) for a in range(3)] for l in range(3)]
+    cand = ops.decode(views, R.STRIDES, anchors, C, thr, cap)
+    torch.cuda.synchronize()
+    offs = cand.img_offsets.cpu().tolist()
+    assert offs[0] == 0
+    total_mismatch = 0
+    for n in range(N):
+        b, s, c = ref[n]
+        gb = cand.boxes[offs[n]:offs[n + 1]].cpu()
+        gs = cand.scores[offs[n]:offs[n + 1]].cpu()
+        gc = cand.classes[offs[n]:offs[n + 1]].cpu().long()
+        if gb.shape[0] == b.shape[0]:
+            assert torch.equal(gc, c), "candidate order / classes differ"
+            assert torch.allclose(gs, s, rtol=1e-4, atol=1e-6)
+            fin = torch.isfinite(b).all(1)
+            assert torch.allclose(gb[fin], b[fin], rtol=1e-4, atol=1e-3)
+        else:
+            # only scores within 1e-5 of the threshold may flip
+            near = int(((torch.cat([s, gs]) - thr).abs() < 1e-5).sum())
+            assert abs(gb.shape[0] - b.shape[0]) <= near
+            total_mismatch += 1
+    assert total_mismatch <= max(1, N // 4)
+    return cand, ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("thr", [0.25, 0.001, 0.5])
+def test_decode_416(cuda, dtype, thr):
+    _check_decode(cuda, 2, 80, [(52, 52), (26, 26), (13, 13)], thr, dtype, seed=11)
+
+
+def test_decode_voc20_rect(cuda):
+    """configs/yolov3.yaml: 20 classes (75 head channels), non-square input."""
+    _check_decode(cuda, 3, 20, [(40, 52), (20, 26), (10, 13)], 0.25, torch.float32, seed=12, ch_pad=80)
+
+
+def test_decode_empty_and_overflow(cuda):
+    from oracle import yolo_ref as R
+    from yolo_amd import ops
+    heads = util.random_heads(2, 80, [(8, 8), (4, 4), (2, 2)], 13, obj_bias=-50.0)
+    views = _heads_to_views(heads, torch.float32, cuda, ops)
+    anchors = [[tuple(map(float, R.cell_anchors()[l][a, 2:] * 2)) for a in range(3)] for l in range(3)]
+    cand = ops.decode(views, R.STRIDES, anchors, 80, 0.25, 16)
+    assert cand.img_offsets.cpu().tolist() == [0, 0, 0]
+    # overflow: true total reported, nothing written past the capacity
+    heads = util.random_heads(2, 80, [(8, 8), (4, 4), (2, 2)], 13, obj_bias=3.0)
+    ref = R.decode_batch(heads, 80, 0.25)
+    views = _heads_to_views(heads, torch.float32, cuda, ops)
+    cap = 100
+    out = ops.Candidates(torch.full((cap + 8, 4), -1.0, device=cuda), torch.full((cap + 8,), -1.0, device=cuda),
+                         torch.full((cap + 8,), -1, dtype=torch.int32, device=cuda),
+                         torch.zeros(3, dtype=torch.int32, device=cuda))
+    ops.decode(views, R.STRIDES, anchors, 80, 0.25, cap, out=out)
+    total = int(out.img_offsets[2])
+    assert total == ref[0][0].shape[0] + ref[1][0].shape[0] and total > cap
+    assert bool((out.scores[cap:] == -1.0).all()) and bool((out.scores[:cap] > 0.25).all())
+
+
+def _run_nms(cuda, per_image, iou_thr, mode, top_k=0, num_classes=80, auto_limit=20000):
+    from yolo_amd import ops
+    boxes = torch.cat([p[0] for p in per_image]).to(cuda)
+    scores = torch.cat([p[1] for p in per_image]).to(cuda)
+    classes = torch.cat([p[2] for p in per_image]).to(torch.int32).to(cuda)
+    counts = [p[0].shape[0] for p in per_image]
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=cuda)
+    M = sum(counts)
+    keep, n_keep = ops.batched_nms(boxes, scores, classes, offs, M, iou_thr, num_classes=num_classes, mode=mode,
+                                   top_k=top_k, auto_limit=auto_limit, keep_stride=max(counts + [1]))
+    torch.cuda.synchronize()
+    return [keep[i, :int(n_keep[i])].cpu().long() for i in range(len(per_image))]
+
+
+def _oracle(p, thr, mode, auto_limit=20000):
+    from oracle import nms_c
+    from yolo_amd import ops
+    b, s, c = p
+    if b.shape[0] == 0:
+        return torch.empty(0, dtype=torch.int64)
+    trick = mode == ops.NMS_COORD_TRICK or (mode == ops.NMS_AUTO and b.numel() <= auto_limit)
+    return nms_c.batched_nms_trick(b, s, c, thr) if trick else nms_c.batched_nms_vanilla(b, s, c, thr)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["per_class", "coord_trick", "auto"])
+def test_nms_random_bit_exact(cuda, mode):
+    per_image = [util.stress_boxes(n, 100 + i, num_classes=20) for i, n in enumerate([2000, 1, 0, 777, 5003, 64, 65])]
+    got = _run_nms(cuda, per_image, 0.5, mode, num_classes=20)
+    for p, g in zip(per_image, got):
+        assert torch.equal(g, _oracle(p, 0.5, mode))
+
+
+def test_nms_stress_608(cuda):
+    """NMS stress configuration: 22743 candidates / image, 80 classes, IoU 0.5 (4 images here)."""
+    per_image = [util.stress_boxes(22743, 100 + i) for i in range(4)]
+    got = _run_nms(cuda, per_image, 0.5, 0)
+    for p, g in zip(per_image, got):
+        assert torch.equal(g, _oracle(p, 0.5, 0))
+    top = _run_nms(cuda, per_image, 0.5, 0, top_k=100)
+    for g, t in zip(got, top):
+        assert torch.equal(g[:100], t)
+
+
+def test_nms_clustered_deep_chains(cuda):
+    per_image = [util.clustered_boxes(300, 76, 7 + i) for i in range(2)]
+    for mode in (0, 1):
+        got = _run_nms(cuda, per_image, 0.5, mode)
+        for p, g in zip(per_image, got):
+            assert torch.equal(g, _oracle(p, 0.5, mode))
+
+
+def test_nms_single_class_long_segment(cuda):
+    """One class only: a 6000-box segment (kept list spills past the LDS list)."""
+    b, s, c = util.stress_boxes(6000, 5, num_classes=1)
+    b = b * 8  # spread out so that many boxes survive
+    got = _run_nms(cuda, [(b, s, c)], 0.5, 0, num_classes=1)
+    ref = _oracle((b, s, c), 0.5, 0)
+    assert ref.numel() > 1000
+    assert torch.equal(got[0], ref)
+
+
+def test_nms_edge_cases(cuda):
+    f = torch.tensor
+    # exact duplicates, equal scores (stable order), IoU exactly at the threshold, zero-area boxes
+    dup = (f([[0., 0, 10, 10]] * 4), f([0.9, 0.9, 0.9, 0.9]), f([1, 1, 2, 1]))
+    thr_edge = (f([[0., 0, 4, 4], [0, 0, 4, 2], [0, 0, 2, 2]]), f([0.9, 0.8, 0.7]), f([0, 0, 0]))  # IoU 0.5, 0.25
+    zero = (f([[5., 5, 5, 5], [5, 5, 5, 5], [0, 0, 1, 1]]), f([0.5, 0.6, 0.7]), f([0, 0, 0]))
+    inf = (f([[-float("inf"), 0, float("inf"), 10], [0., 0, 10, 10], [1, 1, 9, 9]]), f([0.9, 0.8, 0.7]), f([3, 3, 3]))
+    for case in (dup, thr_edge, zero, inf):
+        case = (case[0].float(), case[1].float(), case[2])
+        got = _run_nms(cuda, [case], 0.5, 0, num_classes=4)[0]
+        assert torch.equal(got, _oracle(case, 0.5, 0)), case
+    # hand-derived: IoU exactly 0.5 is NOT suppressed by strict '>'
+    got = _run_nms(cuda, [(thr_edge[0].float(), thr_edge[1].float(), thr_edge[2])], 0.5, 0, num_classes=4)[0]
+    assert got.tolist() == [0, 1, 2]
+    got = _run_nms(cuda, [(dup[0].float(), dup[1].float(), dup[2])], 0.5, 0, num_classes=4)[0]
+    assert got.tolist() == [0, 2]
+
+
+def test_gather_postprocess(cuda):
+    from oracle import yolo_ref as R
+    from yolo_amd import ops
+    per_image = [util.stress_boxes(500, 40 + i, side=416.0) for i in range(3)]
+    boxes = torch.cat([p[0] for p in per_image]).to(cuda)
+    scores = torch.cat([p[1] for p in per_image]).to(cuda)
+    classes = torch.cat([p[2] for p in per_image]).to(torch.int32).to(cuda)
+    offs = torch.tensor([0, 500, 1000, 1500], dtype=torch.int32, device=cuda)
+    keep, n_keep = ops.batched_nms(boxes, scores, classes, offs, 1500, 0.5, num_classes=80, top_k=100)
+    cand = ops.Candidates(boxes, scores, classes, offs)
+    in_hw = torch.tensor([[416, 416], [384, 416], [416, 320]], dtype=torch.int32, device=cuda)
+    out_hw = torch.tensor([[480, 640], [768, 832], [100, 77]], dtype=torch.int32, device=cuda)
+    det, n_det = ops.gather_detections(cand, keep, n_keep, in_hw, out_hw)
+    torch.cuda.synchronize()
+    for i, p in enumerate(per_image):
+        k = keep[i, :int(n_keep[i])].cpu().long()
+        rb, rs, rc = R.detector_postprocess(p[0][k], p[1][k], p[2][k], tuple(in_hw[i].tolist()), *out_hw[i].tolist())
+        d = det[i, :int(n_det[i])].cpu()
+        assert d.shape[0] == rb.shape[0]
+        assert torch.allclose(d[:, :4], rb, rtol=1e-6, atol=1e-4)
+        assert torch.equal(d[:, 4], rs) and torch.equal(d[:, 5].long(), rc)

@@ -1,0 +1,75 @@
+"""ctypes loader for libyolo_hip.so (declared in include/yolo_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing, importing
+anything that computes raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+
+c_int, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
+                                                ctypes.c_void_p, ctypes.c_size_t)
+
+
+class YoloView(ctypes.Structure):
+    """struct yolo_view of include/yolo_hip.h."""
+    _fields_ = [("ptr", c_void_p), ("H", c_int), ("W", c_int), ("halo", c_int),
+                ("ch_total", c_int), ("ch_offset", c_int)]
+
+
+_VP = ctypes.POINTER(YoloView)
+_IP = ctypes.POINTER(c_int)
+_FP = ctypes.POINTER(c_float)
+
+# name -> (restype, argtypes); one entry per declaration in include/yolo_hip.h
+SIGNATURES = {
+    "yolo_last_error": (ctypes.c_char_p, []),
+    "yolo_abi_version": (c_int, []),
+    "yolo_conv_cout_pad": (c_int, [c_int]),
+    "yolo_conv2d_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int,
+                                c_float, c_int, c_int, c_int, c_void_p]),
+    "yolo_stem_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p, c_void_p, _VP,
+                              c_int, c_float, c_int, c_void_p]),
+    "yolo_upsample2x_nhwc": (c_int, [_VP, _VP, c_int, c_int, c_int, c_void_p]),
+    "yolo_decode": (c_int, [_VP, c_int, _IP, _FP, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "yolo_decode_workspace_bytes": (c_size_t, [_VP, c_int, c_int]),
+    "yolo_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_int,
+                                 c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                 c_void_p]),
+    "yolo_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "yolo_gather_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C yolo_amd/csrc` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class YoloHipError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().yolo_last_error().decode("utf-8", "replace")
+        raise YoloHipError(f"{what} failed ({code}): {msg}")

@@ -1,0 +1,386 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): bf16 / f32 MFMA, LDS-staged operand tiles filled
+// by direct global->LDS loads, folded-BatchNorm bias + LeakyReLU (+ residual add, + 2x nearest
+// upsample, + write into a channel slice of a wider buffer) fused into the epilogue.
+//
+// Replaces, per call, detectron2 Conv2d.forward + F.leaky_relu (+ `out += residual`, + nn.Upsample,
+// + torch.cat) of the reference: yolo/modeling/backbone/darknet.py:58-59,113-126 and
+// yolo/modeling/backbone/fpn.py:33-37,66-71,96-100,179.
+//
+// GEMM view: D[channel][pixel] = sum_k W[channel][k] * X[pixel][k], k = (kh, kw, cin) with cin
+// innermost.  Both operand tiles are "row x 128 bytes of k" images in LDS, so weights (MFMA A
+// operand) and activations (MFMA B operand) share one loader and one fragment-read pattern.  With
+// channels on the MFMA row index each lane ends up holding 4 consecutive channels of one pixel,
+// which is what an NHWC epilogue wants.
+#include "common.h"
+
+namespace yolo {
+
+struct ConvParams {
+    const char* x;
+    const char* w;
+    const float* bias;
+    const char* res;
+    char* y;
+    long long x_img_stride;  // bytes
+    long long x_origin;      // bytes: buffer position of logical pixel (-pad,-pad), channel 0
+    int x_row_stride;        // bytes
+    int x_pix_stride;        // bytes
+    long long y_img_stride;  // bytes
+    long long y_origin;      // bytes
+    int y_row_stride, y_pix_stride;
+    long long r_img_stride, r_origin;
+    int r_row_stride, r_pix_stride;
+    int Ho, Wo, M;      // conv output size, M = N*Ho*Wo
+    int stride, ksize;  // conv stride, kernel size
+    int cpt;            // 128-byte k-steps per tap (Cin*esize/128)
+    int nsteps;         // k-steps in total
+    int w_row_bytes;    // bytes per packed weight row
+    int Cout;
+    int n_ctiles, n_ptiles;
+    float slope;
+    int upsample;
+    int y_f32;  // output element type is f32 (else bf16)
+};
+
+constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// T: element type of x / w / residual.  TC x TP: channel x pixel tile of one workgroup (4 waves laid
+// out WC x WP).  TAP2: bf16 with Cin == 32, one k-step spans two filter taps.
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+    static_assert(WC * WP == 4, "4 waves");
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int W_BYTES = TC * ROWB, X_BYTES = TP * ROWB, BUF = W_BYTES + X_BYTES;
+    constexpr int FC = TC / (16 * WC), FP = TP / (16 * WP);
+    constexpr int NWP = TC / 32, NXP = TP / 32;  // 1-KiB pieces per wave per operand
+    static_assert(TP * TC * 4 <= 2 * BUF, "epilogue staging must fit the operand buffers");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // Workgroup -> tile.  Blocks b and b+8 share an XCD (private L2): give each XCD a contiguous
+    // run of tiles, channel tiles of one pixel tile adjacent, so the activation tile is fetched
+    // from HBM once per XCD.
+    int tile_c, tile_p;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_c = logical % p.n_ctiles;
+        tile_p = logical / p.n_ctiles;
+    }
+
+    // ---- loader set-up: each lane owns one 16-byte chunk of NWP weight rows and NXP pixel rows
+    const int lrow = lane >> 3;
+    const int schunk = (lane & 7) ^ lrow;  // source chunk; LDS chunk (lane&7) of row r holds chunk (lane&7)^(r&7)
+    const char* wsrc[NWP];
+    const char* xsrc[NXP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int row = 8 * (wave + 4 * i) + lrow;
+        wsrc[i] = p.w + (size_t)(tile_c * TC + row) * p.w_row_bytes + schunk * 16;
+    }
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+        const int row = 8 * (wave + 4 * i) + lrow;
+        int m = tile_p * TP + row;
+        m = m < p.M ? m : p.M - 1;  // tail rows read a valid pixel; their results are never stored
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        xsrc[i] = p.x + p.x_origin + (long long)n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
+                  (wo * p.stride) * p.x_pix_stride + (TAP2 ? (schunk & 3) : schunk) * 16;
+    }
+    const bool tapsel = (schunk >> 2) != 0;
+
+    // k-step cursor (wave-uniform)
+    int cur_cc = 0, cur_kh = 0, cur_kw = 0, cur_step = 0;
+    auto stage = [&](char* buf) {
+        int xoff;
+        if constexpr (TAP2) {
+            const int t0 = 2 * cur_step;
+            int t1 = t0 + 1;
+            t1 = t1 > 8 ? 8 : t1;  // tap 9 does not exist: its weights are zero, read tap 8 again
+            const int o0 = (t0 / 3) * p.x_row_stride + (t0 % 3) * p.x_pix_stride;
+            const int o1 = (t1 / 3) * p.x_row_stride + (t1 % 3) * p.x_pix_stride;
+            xoff = tapsel ? o1 : o0;
+        } else {
+            xoff = cur_kh * p.x_row_stride + cur_kw * p.x_pix_stride + cur_cc * ROWB;
+        }
+        const int woff = cur_step * ROWB;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + 4 * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + 4 * i) * 1024);
+        ++cur_step;
+        if (++cur_cc == p.cpt) {
+            cur_cc = 0;
+            if (++cur_kw == p.ksize) {
+                cur_kw = 0;
+                ++cur_kh;
+            }
+        }
+    };
+
+    // ---- fragment addressing
+    const int wc = wave / WP, wp = wave % WP;
+    const int l15 = lane & 15, q = lane >> 4, l7 = lane & 7;
+    const int a_base = (wc * (TC / WC) + l15) * ROWB;            // + fc*16*ROWB
+    const int b_base = W_BYTES + (wp * (TP / WP) + l15) * ROWB;  // + fp*16*ROWB
+    const int ko0 = (q ^ l7) << 4;                               // k chunk q, swizzled
+    const int ko1 = ko0 ^ 64;                                    // k chunk 4+q
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const char* buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ko = kk ? ko1 : ko0;
+            if constexpr (BF) {
+                bf16x8 a[FC], b[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) a[i] = *(const bf16x8*)(buf + a_base + i * 16 * ROWB + ko);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) b[j] = *(const bf16x8*)(buf + b_base + j * 16 * ROWB + ko);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                // f32 MFMA 16x16x4 takes ONE k per lane group; element e of each lane's 16-byte
+                // chunk feeds MFMA e, the same k permutation on both operands.
+                f32x4 a[FC], b[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) a[i] = *(const f32x4*)(buf + a_base + i * 16 * ROWB + ko);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) b[j] = *(const f32x4*)(buf + b_base + j * 16 * ROWB + ko);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < FC; ++i)
+#pragma unroll
+                        for (int j = 0; j < FP; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: loads of step s+1 fly while step s is multiplied
+    stage(smem);
+    for (int s = 0; s < p.nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < p.nsteps) stage(smem + ((s + 1) & 1) * BUF);
+        compute(smem + (s & 1) * BUF);
+    }
+    __syncthreads();
+
+    // ---- epilogue 1: bias + LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte
+    //      chunks XOR-swizzled by (pixel & 7)
+    {
+        const int ch0 = wc * (TC / WC) + q * 4;
+        const int px0 = wp * (TP / WP) + l15;
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const int ch = ch0 + i * 16;
+            const f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + ch);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int px = px0 + j * 16;
+                f32x4 v = acc[i][j] + bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
+                *(f32x4*)(smem + px * (TC * 4) + (((ch >> 2) ^ (px & 7)) << 4)) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue 2: one lane = 8 channels of one pixel; whole pixel rows leave as contiguous bytes
+    constexpr int G = TC / 8;       // 8-channel groups per pixel
+    constexpr int PPP = 256 / G;    // pixels per pass
+    const int g = tid % G;
+    const int ch_first = tile_c * TC + g * 8;
+    if (ch_first < p.Cout) {
+#pragma unroll 1
+        for (int pass = 0; pass < TP / PPP; ++pass) {
+            const int px = pass * PPP + tid / G;
+            const int m = tile_p * TP + px;
+            if (m >= p.M) break;
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            const char* sp = smem + px * (TC * 4);
+            f32x4 v0 = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
+            f32x4 v1 = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
+            if (p.res) {
+                const char* rp = p.res + p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                 wo * p.r_pix_stride + (size_t)ch_first * sizeof(T);
+                if constexpr (BF) {
+                    const u32x4 r = *(const u32x4*)rp;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        v0[2 * e] += __uint_as_float(r[e] << 16);
+                        v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                        v1[2 * e] += __uint_as_float(r[2 + e] << 16);
+                        v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
+                    }
+                } else {
+                    v0 += *(const f32x4*)rp;
+                    v1 += *(const f32x4*)(rp + 16);
+                }
+            }
+            const int up = p.upsample ? 2 : 1;
+            char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(ho * up) * p.y_row_stride +
+                       (wo * up) * p.y_pix_stride + (size_t)ch_first * (p.y_f32 ? 4 : 2);
+            u32x4 packed;
+            if (!p.y_f32) {
+                packed[0] = pack_bf16x2(v0[0], v0[1]);
+                packed[1] = pack_bf16x2(v0[2], v0[3]);
+                packed[2] = pack_bf16x2(v1[0], v1[1]);
+                packed[3] = pack_bf16x2(v1[2], v1[3]);
+            }
+            for (int dy = 0; dy < up; ++dy)
+                for (int dx = 0; dx < up; ++dx) {
+                    char* o = yp + dy * p.y_row_stride + dx * p.y_pix_stride;
+                    if (p.y_f32) {
+                        *(f32x4*)o = v0;
+                        *(f32x4*)(o + 16) = v1;
+                    } else {
+                        *(u32x4*)o = packed;
+                    }
+                }
+        }
+    }
+}
+
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2>
+static int launch_conv(const ConvParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * (TC + TP) * ROWB;
+    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int nblocks = p.n_ctiles * p.n_ptiles;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), LDS, stream, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+template <typename T, bool TAP2>
+static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream) {
+    constexpr int TP = 128;
+    p.n_ptiles = (p.M + TP - 1) / TP;
+    p.n_ctiles = (p.Cout + tc - 1) / tc;
+    switch (tc) {
+        case 128: return launch_conv<T, 128, TP, 2, 2, TAP2>(p, stream);
+        case 64: return launch_conv<T, 64, TP, 2, 2, TAP2>(p, stream);
+        default: return launch_conv<T, 32, TP, 1, 4, TAP2>(p, stream);
+    }
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" int yolo_conv_cout_pad(int Cout) { return (Cout + 127) / 128 * 128; }
+
+extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,
+                               const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
+                               int stride, float leaky_slope, int upsample2x, int dtype, int y_dtype, void* stream) {
+    YOLO_REQUIRE(x && y && w_packed && bias, "conv2d: null argument");
+    YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "conv2d: dtype %d", dtype);
+    YOLO_REQUIRE(y_dtype == YOLO_F32 || y_dtype == YOLO_BF16, "conv2d: y_dtype %d", y_dtype);
+    YOLO_REQUIRE(k == 1 || k == 3, "conv2d: kernel size %d (1 or 3)", k);
+    YOLO_REQUIRE(stride == 1 || stride == 2, "conv2d: stride %d (1 or 2)", stride);
+    YOLO_REQUIRE(N > 0 && Cin > 0 && Cout > 0, "conv2d: N/Cin/Cout must be positive");
+    const int pad = (k - 1) / 2;
+    const int es = (int)elem_size(dtype), yes = (int)elem_size(y_dtype);
+    const bool tap2 = dtype == YOLO_BF16 && Cin == 32 && k == 3;
+    if (dtype == YOLO_BF16)
+        YOLO_REQUIRE(Cin % 64 == 0 || tap2, "conv2d bf16: Cin %d must be a multiple of 64 (or 32 with k=3)", Cin);
+    else
+        YOLO_REQUIRE(Cin % 32 == 0, "conv2d f32: Cin %d must be a multiple of 32", Cin);
+    YOLO_REQUIRE(x->halo >= pad, "conv2d: input halo %d < pad %d", x->halo, pad);
+    const int Ho = (x->H + 2 * pad - k) / stride + 1, Wo = (x->W + 2 * pad - k) / stride + 1;
+    const int up = upsample2x ? 2 : 1;
+    YOLO_REQUIRE(y->H == Ho * up && y->W == Wo * up, "conv2d: output view %dx%d, expected %dx%d", y->H, y->W, Ho * up,
+                 Wo * up);
+    const int Cout8 = (Cout + 7) / 8 * 8;
+    YOLO_REQUIRE(x->ch_offset + Cin <= x->ch_total && x->ch_offset % 8 == 0 && x->ch_total % 8 == 0,
+                 "conv2d: bad input channel slice");
+    YOLO_REQUIRE(y->ch_offset + Cout8 <= y->ch_total && y->ch_offset % 8 == 0 && y->ch_total % 8 == 0,
+                 "conv2d: output channel slice [%d,+%d) does not fit %d (8-aligned)", y->ch_offset, Cout8, y->ch_total);
+    YOLO_REQUIRE((long long)N * Ho * Wo < (1ll << 31), "conv2d: too many output pixels");
+    if (residual) {
+        YOLO_REQUIRE(!upsample2x, "conv2d: residual with upsample is not supported");
+        YOLO_REQUIRE(residual->H == Ho && residual->W == Wo && residual->ch_offset % 8 == 0 &&
+                         residual->ch_total % 8 == 0 && residual->ch_offset + Cout8 <= residual->ch_total,
+                     "conv2d: residual view mismatch");
+    }
+
+    ConvParams p{};
+    p.x = (const char*)x->ptr;
+    p.w = (const char*)w_packed;
+    p.bias = bias;
+    p.res = residual ? (const char*)residual->ptr : nullptr;
+    p.y = (char*)y->ptr;
+    const ViewGeom gx = geom_of(*x), gy = geom_of(*y);
+    p.x_img_stride = gx.img_stride * es;
+    p.x_row_stride = gx.row_stride * es;
+    p.x_pix_stride = gx.pix_stride * es;
+    p.x_origin = ((long long)gx.origin - (long long)pad * gx.row_stride - (long long)pad * gx.pix_stride) * es;
+    p.y_img_stride = gy.img_stride * yes;
+    p.y_row_stride = gy.row_stride * yes;
+    p.y_pix_stride = gy.pix_stride * yes;
+    p.y_origin = (long long)gy.origin * yes;
+    if (residual) {
+        const ViewGeom gr = geom_of(*residual);
+        p.r_img_stride = gr.img_stride * es;
+        p.r_row_stride = gr.row_stride * es;
+        p.r_pix_stride = gr.pix_stride * es;
+        p.r_origin = (long long)gr.origin * es;
+    }
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.M = N * Ho * Wo;
+    p.stride = stride;
+    p.ksize = k;
+    const int row_elems = ROWB / es;
+    if (tap2) {
+        p.cpt = 1;
+        p.nsteps = 5;
+        p.w_row_bytes = 5 * ROWB;
+    } else {
+        p.cpt = Cin / row_elems;
+        p.nsteps = k * k * p.cpt;
+        p.w_row_bytes = p.nsteps * ROWB;
+    }
+    p.Cout = Cout;
+    p.slope = leaky_slope;
+    p.upsample = upsample2x ? 1 : 0;
+    p.y_f32 = y_dtype == YOLO_F32;
+
+    const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16) return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st);
+    return dispatch_tc<float, false>(p, tc, st);
+}

@@ -1,0 +1,219 @@
+// First-layer kernel (pixel normalisation + zero padding + 3x3 stem conv + bias + LeakyReLU) and the
+// stand-alone nearest-2x upsample, for gfx950.
+//
+// yolo_stem_fwd replaces DenseDetector.preprocess_image as configured by configs/yolov3.yaml:5-6 and
+// yolo/modeling/backbone/fpn.py:161-163, plus BasicStem.forward (yolo/modeling/backbone/darknet.py:57-60).
+// yolo_upsample2x_nhwc replaces nn.Upsample(2,"nearest") + torch.cat (fpn.py:31,36,179).
+#include "common.h"
+
+namespace yolo {
+
+struct StemParams {
+    const void* img;
+    const float* w;     // [27][32]: (kh,kw,cin) major, output channel minor
+    const float* bias;  // [32]
+    char* y;
+    long long y_img_stride, y_origin;  // bytes
+    int y_row_stride, y_pix_stride;    // bytes
+    int N, Hs, Ws, H, W;
+    float mean[3], stdv[3];
+    float slope;
+};
+
+// One wave = 64 consecutive output pixels of one row; lane = (pixel group pg, channel group cg): it
+// computes 8 channels for the 4 pixels pg, pg+16, pg+32, pg+48, so every store instruction of the
+// wave writes 16 pixels x 64 bytes = 1 KiB of contiguous NHWC output.
+template <typename IMG, bool YF32>
+__global__ void __launch_bounds__(256) stem_kernel(const StemParams p) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * 32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) wl[i] = p.w[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int spans = (p.W + 63) >> 6;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long total = (long long)p.N * p.H * spans;
+    if (wid >= total) return;
+    const int span = (int)(wid % spans);
+    const long long t = wid / spans;
+    const int y = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    const int cg = lane & 3, pg = lane >> 2;
+
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
+
+    const IMG* im = (const IMG*)p.img + (long long)n * 3 * p.Hs * p.Ws;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        const bool yok = iy >= 0 && iy < p.Hs;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const int tapi = (ky * 3 + kx) * 3 + ci;
+                const f32x4 w0 = *(const f32x4*)&wl[tapi * 32 + cg * 8];
+                const f32x4 w1 = *(const f32x4*)&wl[tapi * 32 + cg * 8 + 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = span * 64 + pg + 16 * j + kx - 1;
+                    float v = 0.f;
+                    if (yok && ix >= 0 && ix < p.Ws) {
+                        const float raw = (float)im[((long long)ci * p.Hs + iy) * p.Ws + ix];
+                        v = (raw - p.mean[ci]) / p.stdv[ci];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[j][c] = fmaf(v, w0[c], acc[j][c]);
+                        acc[j][4 + c] = fmaf(v, w1[c], acc[j][4 + c]);
+                    }
+                }
+            }
+        }
+    }
+
+    const f32x4 b0 = *(const f32x4*)&p.bias[cg * 8];
+    const f32x4 b1 = *(const f32x4*)&p.bias[cg * 8 + 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = span * 64 + pg + 16 * j;
+        if (x >= p.W) continue;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = acc[j][c] + (c < 4 ? b0[c] : b1[c - 4]);
+            v[c] = a >= 0.f ? a : a * p.slope;
+        }
+        char* o = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)y * p.y_row_stride +
+                  (long long)x * p.y_pix_stride + cg * 8 * (YF32 ? 4 : 2);
+        if constexpr (YF32) {
+            *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(o + 16) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            u32x4 pk;
+            pk[0] = pack_bf16x2(v[0], v[1]);
+            pk[1] = pack_bf16x2(v[2], v[3]);
+            pk[2] = pack_bf16x2(v[4], v[5]);
+            pk[3] = pack_bf16x2(v[6], v[7]);
+            *(u32x4*)o = pk;
+        }
+    }
+}
+
+struct UpParams {
+    const char* x;
+    char* y;
+    long long x_img_stride, x_origin, y_img_stride, y_origin;  // bytes
+    int x_row_stride, x_pix_stride, y_row_stride, y_pix_stride;
+    int H, W;     // input size
+    int chunks;   // 16-byte chunks per pixel
+    long long total;  // N*H*W*chunks
+};
+
+__global__ void __launch_bounds__(256) upsample2x_kernel(const UpParams p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % p.chunks);
+        long long t = i / p.chunks;
+        const int x = (int)(t % p.W);
+        t /= p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const u32x4 v = *(const u32x4*)(p.x + p.x_origin + n * p.x_img_stride + (long long)y * p.x_row_stride +
+                                        x * p.x_pix_stride + c * 16);
+        char* o = p.y + p.y_origin + n * p.y_img_stride + (long long)(2 * y) * p.y_row_stride +
+                  (2 * x) * p.y_pix_stride + c * 16;
+        *(u32x4*)o = v;
+        *(u32x4*)(o + p.y_pix_stride) = v;
+        *(u32x4*)(o + p.y_row_stride) = v;
+        *(u32x4*)(o + p.y_row_stride + p.y_pix_stride) = v;
+    }
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" int yolo_stem_fwd(const void* img, int img_dtype, int N, int Hs, int Ws, const float* mean_host,
+                             const float* std_host, const float* w, const float* bias, const yolo_view* y, int Cout,
+                             float leaky_slope, int y_dtype, void* stream) {
+    YOLO_REQUIRE(img && mean_host && std_host && w && bias && y, "stem: null argument");
+    YOLO_REQUIRE(img_dtype == 0 || img_dtype == 1, "stem: img_dtype %d (0 = f32, 1 = u8)", img_dtype);
+    YOLO_REQUIRE(Cout == 32, "stem: Cout %d, only 32 output channels are implemented", Cout);
+    YOLO_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hs <= y->H && Ws <= y->W, "stem: image %dx%d does not fit output %dx%d",
+                 Hs, Ws, y->H, y->W);
+    YOLO_REQUIRE(y->ch_offset % 8 == 0 && y->ch_total % 8 == 0 && y->ch_offset + Cout <= y->ch_total,
+                 "stem: bad output channel slice");
+    const int yes = (int)elem_size(y_dtype);
+    const ViewGeom gy = geom_of(*y);
+    StemParams p{};
+    p.img = img;
+    p.w = w;
+    p.bias = bias;
+    p.y = (char*)y->ptr;
+    p.y_img_stride = gy.img_stride * yes;
+    p.y_row_stride = gy.row_stride * yes;
+    p.y_pix_stride = gy.pix_stride * yes;
+    p.y_origin = (long long)gy.origin * yes;
+    p.N = N;
+    p.Hs = Hs;
+    p.Ws = Ws;
+    p.H = y->H;
+    p.W = y->W;
+    for (int i = 0; i < 3; ++i) {
+        p.mean[i] = mean_host[i];
+        p.stdv[i] = std_host[i];
+    }
+    p.slope = leaky_slope;
+    const long long waves = (long long)N * y->H * ((y->W + 63) / 64);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (img_dtype == 0) {
+        if (y_dtype == YOLO_F32)
+            hipLaunchKernelGGL((stem_kernel<float, true>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((stem_kernel<float, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (y_dtype == YOLO_F32)
+            hipLaunchKernelGGL((stem_kernel<unsigned char, true>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((stem_kernel<unsigned char, false>), grid, dim3(256), 0, st, p);
+    }
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+extern "C" int yolo_upsample2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream) {
+    YOLO_REQUIRE(x && y, "upsample2x: null argument");
+    const int es = (int)elem_size(dtype);
+    const int per16 = 16 / es;
+    YOLO_REQUIRE(C > 0 && C % per16 == 0, "upsample2x: C %d must be a multiple of %d", C, per16);
+    YOLO_REQUIRE(y->H == 2 * x->H && y->W == 2 * x->W, "upsample2x: output must be 2x the input");
+    YOLO_REQUIRE(x->ch_offset % per16 == 0 && x->ch_total % per16 == 0 && y->ch_offset % per16 == 0 &&
+                     y->ch_total % per16 == 0 && x->ch_offset + C <= x->ch_total && y->ch_offset + C <= y->ch_total,
+                 "upsample2x: bad channel slice");
+    const ViewGeom gx = geom_of(*x), gy = geom_of(*y);
+    UpParams p{};
+    p.x = (const char*)x->ptr;
+    p.y = (char*)y->ptr;
+    p.x_img_stride = gx.img_stride * es;
+    p.x_row_stride = gx.row_stride * es;
+    p.x_pix_stride = gx.pix_stride * es;
+    p.x_origin = (long long)gx.origin * es;
+    p.y_img_stride = gy.img_stride * es;
+    p.y_row_stride = gy.row_stride * es;
+    p.y_pix_stride = gy.pix_stride * es;
+    p.y_origin = (long long)gy.origin * es;
+    p.H = x->H;
+    p.W = x->W;
+    p.chunks = C / per16;
+    p.total = (long long)N * x->H * x->W * p.chunks;
+    long long blocks = (p.total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}

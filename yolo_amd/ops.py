@@ -1,0 +1,266 @@
+"""Python-side handles of the C-ABI operators of libyolo_hip.so (include/yolo_hip.h).
+
+torch is used for device memory and streams only; every function here forwards raw device pointers
+to a hand-written gfx950 kernel.  There is no fallback: without the library or a GPU these raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import YoloView, check, lib
+
+F32, BF16 = 0, 1
+NMS_PER_CLASS, NMS_COORD_TRICK, NMS_AUTO = 0, 1, 2
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported dtype {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path needs a GPU tensor "
+                           "(there is no CPU fallback)")
+
+
+@dataclass
+class View:
+    """A pixel-major (NHWC) activation buffer with a zero halo, or a channel slice of one.
+
+    ``buf`` has shape [N, H+2*halo, W+2*halo, ch_total]; the view covers channels
+    [ch_offset, ch_offset+C).  Mirrors struct yolo_view.
+    """
+    buf: torch.Tensor
+    H: int
+    W: int
+    halo: int
+    C: int
+    ch_offset: int = 0
+
+    @property
+    def N(self) -> int:
+        return self.buf.shape[0]
+
+    @property
+    def ch_total(self) -> int:
+        return self.buf.shape[3]
+
+    def c(self) -> YoloView:
+        return YoloView(self.buf.data_ptr(), self.H, self.W, self.halo, self.ch_total, self.ch_offset)
+
+    def slice(self, ch_offset: int, C: int) -> "View":
+        assert self.ch_offset + ch_offset + C <= self.ch_total
+        return View(self.buf, self.H, self.W, self.halo, C, self.ch_offset + ch_offset)
+
+    def interior(self) -> torch.Tensor:
+        """Logical [N, H, W, C] tensor (a strided view of the buffer, no copy)."""
+        h = self.halo
+        return self.buf[:, h:h + self.H, h:h + self.W, self.ch_offset:self.ch_offset + self.C]
+
+    def nchw(self) -> torch.Tensor:
+        """Logical [N, C, H, W] tensor (strided view, no copy)."""
+        return self.interior().permute(0, 3, 1, 2)
+
+
+def alloc_view(N: int, H: int, W: int, C: int, halo: int, dtype: torch.dtype, device) -> View:
+    buf = torch.zeros((N, H + 2 * halo, W + 2 * halo, C), dtype=dtype, device=device)
+    return View(buf, H, W, halo, C, 0)
+
+
+def view_from_nchw(x: torch.Tensor, halo: int, dtype: torch.dtype) -> View:
+    """Copy an NCHW tensor into a fresh halo'd NHWC buffer (test / boundary helper)."""
+    N, C, H, W = x.shape
+    v = alloc_view(N, H, W, C, halo, dtype, x.device)
+    v.interior().copy_(x.permute(0, 2, 3, 1))
+    return v
+
+
+# --------------------------------------------------------------------------------------
+# weight packing: eval-mode BatchNorm folded into the conv, K-major rows
+# --------------------------------------------------------------------------------------
+def fold_norm(weight: torch.Tensor, bias: Optional[torch.Tensor], norm: Optional[dict],
+              eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)  (+ conv bias if any).
+    ``norm``: dict(weight, bias, running_mean, running_var) or None."""
+    w = weight.detach().float()
+    cout = w.shape[0]
+    b = bias.detach().float() if bias is not None else torch.zeros(cout, device=w.device)
+    if norm is not None:
+        scale = norm["weight"].float() / torch.sqrt(norm["running_var"].float() + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = (b - norm["running_mean"].float()) * scale + norm["bias"].float()
+    return w, b
+
+
+def pack_conv(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[Cout,Cin,k,k] f32 -> packed [Cout_pad, k*k*Cin (+pad)] rows in ``dtype`` + f32 bias [Cout_pad].
+
+    Row layout is (kh, kw, cin) with cin innermost.  For bf16 with Cin == 32 and k == 3 the row is
+    padded from 9 to 10 taps (zeros) because one 128-byte k-step then spans two taps.
+    """
+    cout, cin, k, _ = weight.shape
+    cpad = lib().yolo_conv_cout_pad(cout)
+    rows = weight.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+    if dtype == torch.bfloat16 and cin == 32 and k == 3:
+        rows = torch.cat([rows, rows.new_zeros(cout, 32)], dim=1)
+    wp = torch.zeros((cpad, rows.shape[1]), dtype=dtype, device=device)
+    wp[:cout] = rows.to(device=device, dtype=dtype)
+    bp = torch.zeros(cpad, dtype=torch.float32, device=device)
+    bp[:cout] = bias.to(device)
+    return wp.contiguous(), bp
+
+
+def pack_stem(weight: torch.Tensor, bias: torch.Tensor, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[Cout,3,3,3] -> [kh,kw,cin,Cout] f32."""
+    return (weight.permute(2, 3, 1, 0).contiguous().float().to(device),
+            bias.float().contiguous().to(device))
+
+
+# --------------------------------------------------------------------------------------
+# operators
+# --------------------------------------------------------------------------------------
+def conv2d_fwd(x: View, w_packed: torch.Tensor, bias: torch.Tensor, y: View, *, cin: int, cout: int,
+               k: int, stride: int, slope: float = 0.1, residual: Optional[View] = None,
+               upsample2x: bool = False) -> None:
+    _require_cuda(x.buf, "conv2d_fwd")
+    xv, yv = x.c(), y.c()
+    rv = residual.c() if residual is not None else None
+    code = lib().yolo_conv2d_fwd(ctypes.byref(xv), _ptr(w_packed), _ptr(bias),
+                                 ctypes.byref(rv) if rv is not None else None, ctypes.byref(yv),
+                                 x.N, cin, cout, k, stride, float(slope), int(upsample2x),
+                                 dtype_code(x.buf.dtype), dtype_code(y.buf.dtype), _stream())
+    check(code, "yolo_conv2d_fwd")
+
+
+def stem_fwd(images: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: View, *,
+             mean: Sequence[float], std: Sequence[float], slope: float = 0.1) -> None:
+    """images: [N,3,Hs,Ws] contiguous, float32 or uint8, values 0..255."""
+    _require_cuda(images, "stem_fwd")
+    assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    if images.dtype == torch.float32:
+        code_dt = 0
+    elif images.dtype == torch.uint8:
+        code_dt = 1
+    else:
+        raise ValueError(f"stem_fwd: image dtype {images.dtype}")
+    N, _, Hs, Ws = images.shape
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    yv = y.c()
+    code = lib().yolo_stem_fwd(_ptr(images), code_dt, N, Hs, Ws, m, s, _ptr(w), _ptr(bias),
+                               ctypes.byref(yv), w.shape[-1], float(slope), dtype_code(y.buf.dtype), _stream())
+    check(code, "yolo_stem_fwd")
+
+
+def upsample2x(x: View, y: View) -> None:
+    _require_cuda(x.buf, "upsample2x")
+    xv, yv = x.c(), y.c()
+    check(lib().yolo_upsample2x_nhwc(ctypes.byref(xv), ctypes.byref(yv), x.N, x.C, dtype_code(x.buf.dtype),
+                                     _stream()), "yolo_upsample2x_nhwc")
+
+
+def _views_array(heads: List[View]):
+    arr = (YoloView * len(heads))()
+    for i, h in enumerate(heads):
+        arr[i] = h.c()
+    return arr
+
+
+def decode_workspace_bytes(heads: List[View]) -> int:
+    return int(lib().yolo_decode_workspace_bytes(_views_array(heads), len(heads), heads[0].N))
+
+
+@dataclass
+class Candidates:
+    boxes: torch.Tensor        # [cap, 4] f32
+    scores: torch.Tensor       # [cap] f32
+    classes: torch.Tensor      # [cap] i32
+    img_offsets: torch.Tensor  # [N+1] i32
+
+
+def decode(heads: List[View], strides: Sequence[int], anchors_wh: Sequence[Sequence[Tuple[float, float]]],
+           num_classes: int, thr: float, cap: int, *, out: Optional[Candidates] = None,
+           workspace: Optional[torch.Tensor] = None) -> Candidates:
+    """heads: level views ordered fine -> coarse (p3, p4, p5)."""
+    dev = heads[0].buf.device
+    _require_cuda(heads[0].buf, "decode")
+    N, L, A = heads[0].N, len(heads), len(anchors_wh[0])
+    if out is None:
+        out = Candidates(torch.empty((cap, 4), dtype=torch.float32, device=dev),
+                         torch.empty((cap,), dtype=torch.float32, device=dev),
+                         torch.empty((cap,), dtype=torch.int32, device=dev),
+                         torch.empty((N + 1,), dtype=torch.int32, device=dev))
+    need = decode_workspace_bytes(heads)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    st = (ctypes.c_int * L)(*[int(s) for s in strides])
+    flat = [float(v) for lvl in anchors_wh for wh in lvl for v in wh]
+    an = (ctypes.c_float * len(flat))(*flat)
+    code = lib().yolo_decode(_views_array(heads), L, st, an, N, A, num_classes, float(thr),
+                             dtype_code(heads[0].buf.dtype), _ptr(out.boxes), _ptr(out.scores),
+                             _ptr(out.classes), _ptr(out.img_offsets), cap, _ptr(workspace),
+                             workspace.numel(), _stream())
+    check(code, "yolo_decode")
+    return out
+
+
+def nms_workspace_bytes(N: int, M: int) -> int:
+    return int(lib().yolo_nms_workspace_bytes(N, M))
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, classes: torch.Tensor, img_offsets: torch.Tensor,
+                M: int, iou_thr: float, *, num_classes: int, mode: int = NMS_PER_CLASS, auto_limit: int = 20000,
+                top_k: int = 0, keep_stride: Optional[int] = None, workspace: Optional[torch.Tensor] = None,
+                keep: Optional[torch.Tensor] = None, n_keep: Optional[torch.Tensor] = None):
+    """Returns (keep [N, keep_stride] i32 image-relative indices, n_keep [N] i32)."""
+    _require_cuda(img_offsets, "batched_nms")
+    dev = img_offsets.device
+    N = img_offsets.numel() - 1
+    if keep_stride is None:
+        keep_stride = top_k if top_k > 0 else max(M, 1)
+    if keep is None:
+        keep = torch.empty((N, keep_stride), dtype=torch.int32, device=dev)
+    if n_keep is None:
+        n_keep = torch.empty((N,), dtype=torch.int32, device=dev)
+    if M > 0:
+        need = nms_workspace_bytes(N, M)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    code = lib().yolo_batched_nms(_ptr(boxes), _ptr(scores), _ptr(classes), _ptr(img_offsets), N, int(M),
+                                  float(iou_thr), int(mode), int(auto_limit), int(top_k), int(num_classes),
+                                  _ptr(keep), keep_stride, _ptr(n_keep),
+                                  _ptr(workspace) if workspace is not None else None,
+                                  workspace.numel() if workspace is not None else 0, _stream())
+    check(code, "yolo_batched_nms")
+    return keep, n_keep
+
+
+def gather_detections(cand: Candidates, keep: torch.Tensor, n_keep: torch.Tensor, in_hw: torch.Tensor,
+                      out_hw: torch.Tensor):
+    """Returns (det [N, keep_stride, 6] f32 = x0,y0,x1,y1,score,class ; n_det [N] i32)."""
+    dev = keep.device
+    N, stride = keep.shape
+    det = torch.empty((N, stride, 6), dtype=torch.float32, device=dev)
+    n_det = torch.empty((N,), dtype=torch.int32, device=dev)
+    code = lib().yolo_gather_detections(_ptr(cand.boxes), _ptr(cand.scores), _ptr(cand.classes),
+                                        _ptr(cand.img_offsets), _ptr(keep), stride, _ptr(n_keep), N,
+                                        _ptr(in_hw), _ptr(out_hw), _ptr(det), _ptr(n_det), _stream())
+    check(code, "yolo_gather_detections")
+    return det, n_det
