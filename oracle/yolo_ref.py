@@ -123,45 +123,73 @@ def randomize_norm_stats(sd: Dict[str, torch.Tensor], seed: int = 1) -> None:
 # --------------------------------------------------------------------------------------
 # backbone + neck  (darknet.py, fpn.py)
 # --------------------------------------------------------------------------------------
-def conv_unit(x: torch.Tensor, sd, name: str, stride: int, pad: int, act: bool = True) -> torch.Tensor:
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.bfloat16().float()
+
+
+def conv_unit(x: torch.Tensor, sd, name: str, stride: int, pad: int, act: bool = True, quant: bool = False,
+              round_out: bool = True, rec: dict | None = None) -> torch.Tensor:
     """detectron2 ``Conv2d.forward`` = F.conv2d then ``self.norm`` (eval BatchNorm), followed by
-    the caller's ``F.leaky_relu(., 0.1)`` (e.g. darknet.py:58-59)."""
+    the caller's ``F.leaky_relu(., 0.1)`` (e.g. darknet.py:58-59).
+
+    ``quant=True`` restates the same layer as a bf16 run of the reference executes it: the
+    batch-norm-folded weights and the layer output are rounded to bfloat16, accumulation in fp32."""
     w = sd[name + ".weight"]
     b = sd.get(name + ".bias")
-    y = F.conv2d(x, w, b, stride=stride, padding=pad)
-    if name + ".norm.weight" in sd:
-        y = F.batch_norm(y, sd[name + ".norm.running_mean"], sd[name + ".norm.running_var"],
-                         sd[name + ".norm.weight"], sd[name + ".norm.bias"], False, 0.1, BN_EPS)
+    has_norm = name + ".norm.weight" in sd
+    if not quant:
+        y = F.conv2d(x, w, b, stride=stride, padding=pad)
+        if has_norm:
+            y = F.batch_norm(y, sd[name + ".norm.running_mean"], sd[name + ".norm.running_var"],
+                             sd[name + ".norm.weight"], sd[name + ".norm.bias"], False, 0.1, BN_EPS)
+    else:
+        bias = b if b is not None else torch.zeros(w.shape[0])
+        if has_norm:
+            scale = sd[name + ".norm.weight"] / torch.sqrt(sd[name + ".norm.running_var"] + BN_EPS)
+            w = w * scale.view(-1, 1, 1, 1)
+            bias = (bias - sd[name + ".norm.running_mean"]) * scale + sd[name + ".norm.bias"]
+        y = F.conv2d(x, _bf16(w), bias, stride=stride, padding=pad)
     if act:
         y = F.leaky_relu(y, LEAKY)
+    if quant and round_out:
+        y = _bf16(y)
+    if rec is not None:  # per-layer record for layer-by-layer ("teacher forced") parity tests
+        rec[name] = dict(x=x, y=y, stride=stride, act=act)
     return y
 
 
-def residual_block(x, sd, p: str, downsample: bool):
+def residual_block(x, sd, p: str, downsample: bool, quant: bool = False, rec: dict | None = None):
     """ResidualBlock.forward, darknet.py:113-126: the add comes AFTER conv2's activation."""
     if downsample:
-        x = conv_unit(x, sd, p + ".downsample", 2, 1)  # :114-116
+        x = conv_unit(x, sd, p + ".downsample", 2, 1, quant=quant, rec=rec)  # :114-116
     residual = x.clone()  # :118
-    out = conv_unit(x, sd, p + ".conv1", 1, 0)  # :119-120
-    out = conv_unit(out, sd, p + ".conv2", 1, 1)  # :122-123
-    out += residual  # :125
+    out = conv_unit(x, sd, p + ".conv1", 1, 0, quant=quant, rec=rec)  # :119-120
+    out = conv_unit(out, sd, p + ".conv2", 1, 1, quant=quant, round_out=False, rec=rec)  # :122-123
+    out = out + residual  # :125 (`out += residual`)
+    out = _bf16(out) if quant else out
+    if rec is not None:
+        rec[p + ".conv2"].update(residual=residual, y=out)
     return out
 
 
-def darknet_forward(x, sd, prefix="backbone.", blocks=(1, 2, 8, 8, 4)):
+def darknet_forward(x, sd, prefix="backbone.", blocks=(1, 2, 8, 8, 4), quant: bool = False, rec: dict | None = None):
     """DarkNet.forward darknet.py:203-226 -> {res3,res4,res5}."""
-    x = conv_unit(x, sd, prefix + "bottom_up.stem.conv", 1, 1)  # BasicStem.forward :57-60
+    if quant:
+        x = _bf16(x)
+    x = conv_unit(x, sd, prefix + "bottom_up.stem.conv", 1, 1, quant=quant, rec=rec)  # BasicStem.forward :57-60
     outs = {}
     for si, nb in enumerate(blocks, start=1):
         for b in range(nb):
-            x = residual_block(x, sd, f"{prefix}bottom_up.res{si}.{b}", b == 0)
+            x = residual_block(x, sd, f"{prefix}bottom_up.res{si}.{b}", b == 0, quant, rec)
         outs[f"res{si}"] = x
     return outs
 
 
-def fpn_forward(x, sd, prefix="backbone.", blocks=(1, 2, 8, 8, 4), taps: dict | None = None):
-    """DarkNetFPN.forward fpn.py:165-185 -> {"p3","p4","p5"} raw head tensors (NCHW)."""
-    bu = darknet_forward(x, sd, prefix, blocks)
+def fpn_forward(x, sd, prefix="backbone.", blocks=(1, 2, 8, 8, 4), taps: dict | None = None, quant: bool = False,
+                quant_heads: bool = False, rec: dict | None = None):
+    """DarkNetFPN.forward fpn.py:165-185 -> {"p3","p4","p5"} raw head tensors (NCHW).
+    ``quant``: bf16 restatement (see conv_unit); ``quant_heads`` also rounds the head tensors."""
+    bu = darknet_forward(x, sd, prefix, blocks, quant, rec)
     if taps is not None:
         taps.update(bu)
     feats = ["res3", "res4", "res5"]
@@ -173,12 +201,13 @@ def fpn_forward(x, sd, prefix="backbone.", blocks=(1, 2, 8, 8, 4), taps: dict | 
             f = torch.cat([topdown, f], dim=1)  # :179 -- upsampled first
         for i in range(5):  # LateralBlock.forward :66-71
             k = 1 if i % 2 == 0 else 3
-            f = conv_unit(f, sd, f"{prefix}fpn_lateral{idx}.blocks.{i}", 1, (k - 1) // 2)
-        o = conv_unit(f, sd, f"{prefix}fpn_output{idx}.conv", 1, 1)  # OutputBlock :96-98
-        o = conv_unit(o, sd, f"{prefix}fpn_output{idx}.head", 1, 0, act=False)  # :99
+            f = conv_unit(f, sd, f"{prefix}fpn_lateral{idx}.blocks.{i}", 1, (k - 1) // 2, quant=quant, rec=rec)
+        o = conv_unit(f, sd, f"{prefix}fpn_output{idx}.conv", 1, 1, quant=quant, rec=rec)  # OutputBlock :96-98
+        o = conv_unit(o, sd, f"{prefix}fpn_output{idx}.head", 1, 0, act=False, quant=quant,
+                      round_out=quant_heads, rec=rec)  # :99
         result.insert(0, o)  # :177,181
         if idx < 2:  # UpSampleBlock.forward :33-37
-            t = conv_unit(f, sd, f"{prefix}fpn_upsample{idx}.conv", 1, 0)
+            t = conv_unit(f, sd, f"{prefix}fpn_upsample{idx}.conv", 1, 0, quant=quant, rec=rec)
             topdown = F.interpolate(t, scale_factor=2.0, mode="nearest")
     return dict(zip(["p3", "p4", "p5"], result))
 

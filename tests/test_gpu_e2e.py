@@ -1,0 +1,160 @@
+"""End-to-end GPU parity: the whole Darknet-53 + FPN plan and the full detector against the CPU oracle
+(oracle/yolo_ref.py: restatement of yolo/modeling/backbone/{darknet,fpn}.py and
+yolo/modeling/meta_arch/yolo.py of the reference) on the same state dict and the same synthetic images.
+
+Tolerances, as max|err| / max|ref| per tensor:
+  * fp32 plan against the fp32 oracle: 1e-3 on every stage output and head (measured: < 3e-5);
+  * bf16, layer by layer (test_every_layer_bf16_teacher_forced): each of the 75 layers of the real network,
+    fed the oracle's input for that layer, meets 5e-2 against the oracle's bf16 restatement (weights and
+    layer outputs rounded to bfloat16, fp32 accumulation -- what a bf16 run of the reference computes);
+  * bf16, whole chain: a randomly initialised, BatchNorm-calibrated Darknet-53 roughly doubles any
+    perturbation per stage (the fp32 GPU-vs-CPU difference grows 9e-7 -> 2e-5 the same way), so a single
+    flipped bf16 rounding early on is visible at the heads.  The chained bf16 plan is therefore bounded by
+    1e-1 against the bf16 restatement (measured 4e-2 .. 7e-2 at the heads) and 0.3 in relative L2 against
+    the fp32 oracle; that growth is a property of bf16 on this network, not of the kernels.
+"""
+import pytest
+import torch
+
+import workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    return float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
+
+
+def _rel_l2(got, ref):
+    return float((got.double() - ref.double()).norm() / ref.double().norm())
+
+
+def _check(got, ref, dtype, name, ref32=None):
+    if dtype == torch.float32:
+        assert _rel(got, ref) < 1e-3, name
+    else:
+        assert _rel(got, ref) < 1e-1, (name, _rel(got, ref))
+        assert _rel_l2(got, ref32) < 0.3, (name, _rel_l2(got, ref32))
+
+
+@pytest.fixture(scope="module")
+def calibrated(cuda):
+    model, cfg = workload.calibrated_model(size=256, calib_batch=4, config="yolov3-aug.yaml", dtype="f32")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return model, cfg, sd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_backbone_neck_heads(cuda, calibrated, dtype):
+    from oracle import yolo_ref as R
+    model, cfg, sd = calibrated
+    model.backbone.compute_dtype = dtype
+    imgs = workload.synthetic_images(2, 96, 128, seed=5)
+    x = imgs.float() / 255.0
+    taps, taps32 = {}, {}
+    with torch.no_grad():
+        ref32 = R.fpn_forward(x, sd, taps=taps32)
+        ref = R.fpn_forward(x, sd, taps=taps, quant=dtype == torch.bfloat16)
+    out = model.backbone(x.to(cuda))
+    torch.cuda.synchronize()
+    plan = model.backbone.engine().plan(2, 96, 128)
+    for name in ("res3", "res4", "res5"):
+        got = plan.taps[name].nchw().float().cpu()
+        _check(got, taps[name], dtype, name, taps32[name])
+    for name in ("p3", "p4", "p5"):
+        assert out[name].shape == ref[name].shape
+        _check(out[name].float().cpu(), ref[name], dtype, name, ref32[name])
+    model.backbone.compute_dtype = torch.float32
+
+
+def _match(det, ref_b, ref_s, ref_c):
+    """fraction of reference detections that have a twin (same class, IoU > 0.98, score within 2e-3)."""
+    if ref_b.shape[0] == 0:
+        return 1.0 if det.shape[0] == 0 else 0.0
+    hit = 0
+    for b, s, c in zip(ref_b, ref_s, ref_c):
+        same = (det[:, 5].long() == int(c)) & ((det[:, 4] - s).abs() < 2e-3)
+        if not same.any():
+            continue
+        d = det[same, :4]
+        ix = (torch.min(d[:, 2], b[2]) - torch.max(d[:, 0], b[0])).clamp(min=0)
+        iy = (torch.min(d[:, 3], b[3]) - torch.max(d[:, 1], b[1])).clamp(min=0)
+        inter = ix * iy
+        union = (d[:, 2] - d[:, 0]) * (d[:, 3] - d[:, 1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
+        hit += bool((inter / union > 0.98).any())
+    return hit / ref_b.shape[0]
+
+
+def test_detector_end_to_end_f32(cuda, calibrated):
+    """model(batched_inputs) in fp32 against the oracle's inference(): ragged batch, output rescale."""
+    from oracle import nms_c, yolo_ref as R
+    model, cfg, sd = calibrated
+    model.backbone.compute_dtype = torch.float32
+    # lower the objectness prior so that the tiny test images still produce detections
+    imgs = [workload.synthetic_images(1, 96, 128, seed=21)[0], workload.synthetic_images(1, 64, 96, seed=22)[0]]
+    out_sizes = [(192, 256), (64, 96)]
+    thr = 0.02
+    model.test_score_thresh = thr
+    inputs = [dict(image=i, height=o[0], width=o[1]) for i, o in zip(imgs, out_sizes)]
+    res = model(inputs)
+    with torch.no_grad():
+        ref = R.inference([i.float() for i in imgs], sd, 80, thr, cfg.MODEL.YOLOV3.TEST_NMS_THRESH,
+                          out_sizes=out_sizes, nms_fn=nms_c.nms, device_kind="gpu")
+    total = 0
+    for r, (rb, rs, rc), o in zip(res, ref, out_sizes):
+        inst = r["instances"]
+        assert inst.image_size == o
+        det = torch.cat([inst.pred_boxes.tensor, inst.scores[:, None], inst.pred_classes[:, None].float()], 1).cpu()
+        assert abs(det.shape[0] - rb.shape[0]) <= max(2, rb.shape[0] // 10)
+        assert _match(det, rb, rs, rc) >= 0.9
+        total += rb.shape[0]
+    assert total > 0, "test inputs produced no detections; the comparison would be vacuous"
+
+
+def test_per_module_forward_matches_plan(cuda, calibrated):
+    """Operator-level seam: calling ResidualBlock / LateralBlock modules one by one gives the plan's result."""
+    from oracle import yolo_ref as R
+    model, cfg, sd = calibrated
+    x = (workload.synthetic_images(1, 64, 64, seed=9).float() / 255.0)
+    bu = model.backbone.bottom_up
+    y = bu.stem(x.to(cuda))
+    y = bu.res1(y)
+    with torch.no_grad():
+        r = R.conv_unit(x, sd, "backbone.bottom_up.stem.conv", 1, 1)
+        r = R.residual_block(r, sd, "backbone.bottom_up.res1.0", True)
+    assert _rel(y.float().cpu(), r) < 1e-3
+
+
+def test_every_layer_bf16_teacher_forced(cuda, calibrated):
+    """Each conv of the real network in bf16, fed the oracle's own input to that layer."""
+    from oracle import yolo_ref as R
+    from yolo_amd import ops
+    model, cfg, sd = calibrated
+    x = workload.synthetic_images(2, 128, 160, seed=5).float() / 255.0
+    rec = {}
+    with torch.no_grad():
+        R.fpn_forward(x, sd, quant=True, rec=rec)
+    convs = dict(model.backbone.darknet_modules())
+    worst = 0.0
+    assert len(rec) == 75
+    for name, conv in convs.items():
+        r = rec["backbone." + name]
+        wf, bf = conv.folded()
+        if conv.in_channels == 3:
+            w, b = ops.pack_stem(wf, bf, cuda)
+            y = ops.alloc_view(2, 128, 160, conv.out_channels, 1, torch.bfloat16, cuda)
+            ops.stem_fwd((x * 255.0).to(cuda).contiguous(), w, b, y, mean=(0, 0, 0), std=(255.0, 255.0, 255.0))
+        else:
+            w, b = ops.pack_conv(wf, bf, torch.bfloat16, cuda)
+            xv = ops.view_from_nchw(r["x"].to(cuda), 1, torch.bfloat16)
+            is_head = name.endswith(".head")
+            y = ops.alloc_view(2, r["y"].shape[2], r["y"].shape[3], (conv.out_channels + 7) // 8 * 8, 0,
+                               torch.float32 if is_head else torch.bfloat16, cuda)
+            rv = ops.view_from_nchw(r["residual"].to(cuda), 0, torch.bfloat16) if "residual" in r else None
+            ops.conv2d_fwd(xv, w, b, y, cin=conv.in_channels, cout=conv.out_channels, k=conv.kernel_size,
+                           stride=conv.stride, slope=0.1 if r["act"] else 1.0, residual=rv)
+        torch.cuda.synchronize()
+        err = _rel(y.nchw()[:, :conv.out_channels].float().cpu(), r["y"])
+        worst = max(worst, err)
+        assert err < 5e-2, (name, err)
+    assert worst < 2e-2  # one bf16 ulp at the top of the range is 2^-8; typical worst layer is ~4e-3

@@ -104,6 +104,102 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemParams p) {
     }
 }
 
+// bf16-output stem on the matrix cores.  The normalised image tile is staged in LDS as bf16 "RGB0"
+// pixels (8 bytes each); with k ordered (ky, 4 pixels x-1..x+2, 4 channels) every 8-element MFMA k
+// chunk of a pixel is 16 contiguous LDS bytes, so the im2col operand needs no gather.  k = 3*16 = 48 is
+// padded to 64 (two 16x16x32 MFMAs); the 4th pixel and 4th channel meet zero weights.  Output channel
+// rows are permuted so that each lane ends up with 8 consecutive channels: one 16-byte store per lane,
+// 1 KiB contiguous per wave.
+constexpr int ST_TH = 8, ST_TW = 64, ST_LW = ST_TW + 4;
+
+template <typename IMG>
+__global__ void __launch_bounds__(256) stem_mfma_kernel(const StemParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned long long tile[(ST_TH + 2) * ST_LW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * ST_TW, y0 = blockIdx.y * ST_TH, n = blockIdx.z;
+    const IMG* im = (const IMG*)p.img + (long long)n * 3 * p.Hs * p.Ws;
+    for (int i = tid; i < (ST_TH + 2) * ST_LW; i += 256) {
+        const int r = i / ST_LW, c = i - r * ST_LW;
+        const int iy = y0 + r - 1, ix = x0 + c - 1;
+        unsigned long long v = 0;
+        if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) {
+            const long long o = (long long)iy * p.Ws + ix;
+            const long long plane = (long long)p.Hs * p.Ws;
+            const float r0 = ((float)im[o] - p.mean[0]) / p.stdv[0];
+            const float r1 = ((float)im[plane + o] - p.mean[1]) / p.stdv[1];
+            const float r2 = ((float)im[2 * plane + o] - p.mean[2]) / p.stdv[2];
+            v = (unsigned long long)pack_bf16x2(r0, r1) | ((unsigned long long)pack_bf16x2(r2, 0.f) << 32);
+        }
+        tile[i] = v;
+    }
+    // weight fragments: A[row m][k], row m of fragment f <-> channel 8*(m>>2) + 4*f + (m&3)
+    const int l15 = lane & 15, q = lane >> 4;
+    bf16x8 afrag[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int ch = 8 * (l15 >> 2) + 4 * f + (l15 & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = 4 * s + q;  // k chunk: ky = c/2, pixels 2*(c&1), 2*(c&1)+1
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ky = c >> 1, kx = 2 * (c & 1) + (j >> 2), ci = j & 3;
+                float w = 0.f;
+                if (ky < 3 && kx < 3 && ci < 3) w = p.w[((ky * 3 + kx) * 3 + ci) * 32 + ch];
+                afrag[f][s][j] = (bf16_t)w;
+            }
+        }
+    }
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias[j] = p.bias[8 * q + j];
+    __syncthreads();
+
+    const char* tb = (const char*)tile;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = wave * 2 + (it >> 2);
+        const int x = (it & 3) * 16 + l15;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = 4 * s + q;
+            bf16x8 b;
+            if (c < 6) {
+                const char* a = tb + ((row + (c >> 1)) * ST_LW + x + 2 * (c & 1)) * 8;
+                const u32x2 lo = *(const u32x2*)a;
+                const u32x2 hi = *(const u32x2*)(a + 8);
+                const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                b = __builtin_bit_cast(bf16x8, v);
+            } else {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                b = __builtin_bit_cast(bf16x8, z);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][s], b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[1][s], b, acc1, 0, 0, 0);
+        }
+        const int gx = x0 + x, gy = y0 + row;
+        if (gx < p.W && gy < p.H) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc0[j] + bias[j];
+                v[4 + j] = acc1[j] + bias[4 + j];
+            }
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = v[2 * j] >= 0.f ? v[2 * j] : v[2 * j] * p.slope;
+                const float b2 = v[2 * j + 1] >= 0.f ? v[2 * j + 1] : v[2 * j + 1] * p.slope;
+                pk[j] = pack_bf16x2(a, b2);
+            }
+            char* o = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)gy * p.y_row_stride +
+                      (long long)gx * p.y_pix_stride + q * 16;
+            *(u32x4*)o = pk;
+        }
+    }
+}
+
 struct UpParams {
     const char* x;
     char* y;
@@ -168,19 +264,21 @@ extern "C" int yolo_stem_fwd(const void* img, int img_dtype, int N, int Hs, int 
         p.stdv[i] = std_host[i];
     }
     p.slope = leaky_slope;
-    const long long waves = (long long)N * y->H * ((y->W + 63) / 64);
-    const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (img_dtype == 0) {
-        if (y_dtype == YOLO_F32)
+    if (y_dtype == YOLO_BF16) {
+        const dim3 grid((y->W + ST_TW - 1) / ST_TW, (y->H + ST_TH - 1) / ST_TH, N);
+        YOLO_REQUIRE(N <= 65535, "stem: batch %d > 65535", N);
+        if (img_dtype == 0)
+            hipLaunchKernelGGL((stem_mfma_kernel<float>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((stem_mfma_kernel<unsigned char>), grid, dim3(256), 0, st, p);
+    } else {
+        const long long waves = (long long)N * y->H * ((y->W + 63) / 64);
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        if (img_dtype == 0)
             hipLaunchKernelGGL((stem_kernel<float, true>), grid, dim3(256), 0, st, p);
         else
-            hipLaunchKernelGGL((stem_kernel<float, false>), grid, dim3(256), 0, st, p);
-    } else {
-        if (y_dtype == YOLO_F32)
             hipLaunchKernelGGL((stem_kernel<unsigned char, true>), grid, dim3(256), 0, st, p);
-        else
-            hipLaunchKernelGGL((stem_kernel<unsigned char, false>), grid, dim3(256), 0, st, p);
     }
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;

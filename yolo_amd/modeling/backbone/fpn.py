@@ -1,0 +1,159 @@
+"""YOLOv3 neck + head convolutions on top of Darknet-53: module tree with the reference's parameter
+names (yolo/modeling/backbone/fpn.py:20-215).  ``DarkNetFPN.forward`` runs the whole network through
+the fused inference plan of ``yolo_amd/engine.py``."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from ..registry import BACKBONE_REGISTRY, build_anchor_generator
+from .darknet import LEAKY_SLOPE, Backbone, CNNBlockBase, build_darknet53_backbone
+from .layers import Conv2d, c2_msra_fill, get_norm
+
+__all__ = ["DarkNetFPN", "build_darknet53_fpn_backbone"]
+
+
+class UpSampleBlock(CNNBlockBase):
+    """1x1 conv (C -> C/2) + BN + LeakyReLU + nearest 2x (reference fpn.py:20-37; its conv keeps the
+    framework-default initialisation)."""
+
+    def __init__(self, in_channels, out_channels, *, norm):
+        super().__init__(in_channels, out_channels, stride=1)
+        self.conv = Conv2d(in_channels, out_channels, 1, stride=1, padding=0, bias=False,
+                           norm=get_norm(norm, out_channels))
+
+    def forward(self, x):
+        out = self.conv(x, slope=LEAKY_SLOPE)
+        return out.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+class LateralBlock(CNNBlockBase):
+    """Five conv+BN+LeakyReLU layers alternating 1x1 (-> c) and 3x3 (-> 2c) (reference fpn.py:40-71)."""
+
+    def __init__(self, in_channels, out_channels, *, norm):
+        super().__init__(in_channels, out_channels, stride=1)
+        self.blocks = nn.ModuleList()
+        use_bias = norm == ""
+        cin, cout = in_channels, out_channels
+        for i in range(5):
+            k = 1 if i % 2 == 0 else 3
+            if i > 0:
+                cin, cout = cout, (out_channels if k == 1 else out_channels * 2)
+            self.blocks.append(Conv2d(cin, cout, k, stride=1, padding=(k - 1) // 2, bias=use_bias,
+                                      norm=get_norm(norm, cout)))
+        for conv in self.blocks:
+            c2_msra_fill(conv)
+
+    def forward(self, x):
+        for conv in self.blocks:
+            x = conv(x, slope=LEAKY_SLOPE)
+        return x
+
+
+class OutputBlock(CNNBlockBase):
+    """3x3 conv (c -> 2c) + BN + LeakyReLU, then the linear 1x1 head with bias (reference fpn.py:74-100)."""
+
+    def __init__(self, in_channels, out_channels, *, norm):
+        super().__init__(in_channels, out_channels, stride=1)
+        self.conv = Conv2d(in_channels, in_channels * 2, 3, stride=1, padding=1, bias=False,
+                           norm=get_norm(norm, in_channels * 2))
+        self.head = Conv2d(in_channels * 2, out_channels, 1, stride=1, padding=0, bias=True)
+        c2_msra_fill(self.conv)
+        c2_msra_fill(self.head)
+
+    def forward(self, x):
+        return self.head(self.conv(x, slope=LEAKY_SLOPE), slope=1.0)
+
+
+class DarkNetFPN(Backbone):
+    def __init__(self, bottom_up, in_features, out_channels, norm="", *, num_classes=None, anchors_wh=None):
+        super().__init__()
+        self.bottom_up = bottom_up
+        self.in_features = in_features
+        shapes = bottom_up.output_shape()
+        chans = [shapes[f].channels for f in in_features]
+        self.output_channels = out_channels
+        self.lateral_convs, self.output_convs, self.upsample_convs = [], [], []
+        for idx, c_in in enumerate(reversed(chans)):  # stride-32 level first
+            lat = c_in // 2
+            if idx > 0:
+                c_in += c_in // 2  # concat with the upsampled coarser level
+            lateral = LateralBlock(c_in, lat, norm=norm)
+            self.add_module(f"fpn_lateral{idx}", lateral)
+            self.lateral_convs.append(lateral)
+            output = OutputBlock(lat, out_channels, norm=norm)
+            self.add_module(f"fpn_output{idx}", output)
+            self.output_convs.append(output)
+            if idx + 1 < len(chans):
+                up = UpSampleBlock(lat, lat // 2, norm=norm)
+                self.add_module(f"fpn_upsample{idx}", up)
+                self.upsample_convs.append(up)
+        self._out_features = ["p3", "p4", "p5"]
+        self._out_feature_channels = {k: shapes[f].channels for f, k in zip(in_features, self._out_features)}
+        self._out_feature_strides = {k: shapes[f].stride for f, k in zip(in_features, self._out_features)}
+        # engine settings (not part of the state dict)
+        self._num_classes = num_classes
+        self._anchors_wh = anchors_wh
+        self.compute_dtype = torch.bfloat16
+        self.head_dtype = torch.float32
+        self._engine = None
+        self._engine_key = None
+
+    @property
+    def size_divisibility(self):
+        return 32
+
+    def darknet_modules(self):
+        """(name, conv) in Darknet file order (reference fpn.py:187-190)."""
+        for name, m in self.named_modules():
+            if isinstance(m, Conv2d):
+                yield name, m
+
+    # ---- fused execution -------------------------------------------------------------------
+    def engine(self):
+        from ...engine import Yolov3Engine
+        key = (self.compute_dtype, self.head_dtype, next(self.parameters()).device,
+               tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
+        if self._engine is None or self._engine_key != key:
+            if self._num_classes is None:
+                raise RuntimeError("DarkNetFPN was built without num_classes / anchors; use "
+                                   "build_darknet53_fpn_backbone(cfg, ...)")
+            self._engine = Yolov3Engine(self, num_classes=self._num_classes, anchors_wh=self._anchors_wh,
+                                        strides=[self._out_feature_strides[k] for k in self._out_features],
+                                        dtype=self.compute_dtype, head_dtype=self.head_dtype,
+                                        blocks=self.bottom_up.blocks_per_stage)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """x: normalised images [N, 3, H, W] float32 with H, W multiples of 32.  Returns the raw head
+        tensors {"p3","p4","p5"} as [N, A*(5+C), H/s, W/s] (strided views of the plan's NHWC buffers; they
+        are overwritten by the next call with the same input shape)."""
+        if self.training:
+            raise NotImplementedError("training is not built on the HIP path yet; call .eval()")
+        if not x.is_cuda:
+            raise RuntimeError("yolo_amd runs on MI355X only: input is on the CPU and there is no CPU fallback")
+        assert x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0, "H, W must be multiples of size_divisibility (32)"
+        P = self.engine().run_backbone(x.float())
+        return {k: v.nchw() for k, v in zip(self._out_features, P.heads)}
+
+
+@BACKBONE_REGISTRY.register()
+def build_darknet53_fpn_backbone(cfg, input_shape):
+    bottom_up = build_darknet53_backbone(cfg, input_shape)
+    in_features = cfg.MODEL.DARKNET.OUT_FEATURES
+    shapes = bottom_up.output_shape()
+    gen = build_anchor_generator(cfg, [shapes[f] for f in in_features])
+    num_anchors = gen.num_cell_anchors
+    assert len(set(num_anchors)) == 1, "Using different number of anchors between levels is not currently supported!"
+    num_classes = cfg.MODEL.YOLOV3.NUM_CLASSES
+    out_channels = (4 + 1 + num_classes) * num_anchors[0]
+    fpn = DarkNetFPN(bottom_up, in_features, out_channels, norm=cfg.MODEL.DARKNET.NORM, num_classes=num_classes,
+                     anchors_wh=gen.anchors_wh())
+    hip = cfg.MODEL.get("HIP", None)
+    if hip is not None:
+        fpn.compute_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[hip.DTYPE]
+        fpn.head_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[hip.HEAD_DTYPE]
+    return fpn

@@ -1,0 +1,181 @@
+"""Minimal tensor containers with the interface the reference's model boundary uses
+(detectron2.structures.Boxes / Instances / ImageList and detectron2.layers.ShapeSpec as consumed at
+yolo/modeling/meta_arch/yolo.py:19,381-383 and tools/inference.py:43-44)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+
+@dataclass
+class ShapeSpec:
+    channels: Optional[int] = None
+    height: Optional[int] = None
+    width: Optional[int] = None
+    stride: Optional[int] = None
+
+
+class Boxes:
+    """N x 4 XYXY absolute boxes."""
+
+    def __init__(self, tensor: torch.Tensor):
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.as_tensor(tensor, dtype=torch.float32)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((-1, 4)).to(torch.float32)
+        assert tensor.dim() == 2 and tensor.size(-1) == 4, tensor.size()
+        self.tensor = tensor
+
+    def clone(self) -> "Boxes":
+        return Boxes(self.tensor.clone())
+
+    def to(self, device) -> "Boxes":
+        return Boxes(self.tensor.to(device=device))
+
+    def area(self) -> torch.Tensor:
+        b = self.tensor
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    def clip(self, box_size: Tuple[int, int]) -> None:
+        h, w = box_size
+        x1 = self.tensor[:, 0].clamp(min=0, max=w)
+        y1 = self.tensor[:, 1].clamp(min=0, max=h)
+        x2 = self.tensor[:, 2].clamp(min=0, max=w)
+        y2 = self.tensor[:, 3].clamp(min=0, max=h)
+        self.tensor = torch.stack((x1, y1, x2, y2), dim=-1)
+
+    def nonempty(self, threshold: float = 0.0) -> torch.Tensor:
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def scale(self, scale_x: float, scale_y: float) -> None:
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
+    def get_centers(self) -> torch.Tensor:
+        return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
+
+    def __getitem__(self, item) -> "Boxes":
+        if isinstance(item, int):
+            return Boxes(self.tensor[item].view(1, -1))
+        return Boxes(self.tensor[item])
+
+    def __len__(self) -> int:
+        return self.tensor.shape[0]
+
+    def __repr__(self) -> str:
+        return "Boxes(" + str(self.tensor) + ")"
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @classmethod
+    def cat(cls, boxes_list: List["Boxes"]) -> "Boxes":
+        if len(boxes_list) == 0:
+            return cls(torch.empty(0))
+        return cls(torch.cat([b.tensor for b in boxes_list], dim=0))
+
+
+class Instances:
+    """Per-image fields of equal length, addressed as attributes."""
+
+    def __init__(self, image_size: Tuple[int, int], **kwargs: Any):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_fields", {})
+        for k, v in kwargs.items():
+            self.set(k, v)
+
+    @property
+    def image_size(self) -> Tuple[int, int]:
+        return self._image_size
+
+    def __setattr__(self, name: str, val: Any) -> None:
+        if name.startswith("_"):
+            object.__setattr__(self, name, val)
+        else:
+            self.set(name, val)
+
+    def __getattr__(self, name: str) -> Any:
+        if name == "_fields" or name not in self._fields:
+            raise AttributeError(f"Cannot find field '{name}' in the given Instances!")
+        return self._fields[name]
+
+    def set(self, name: str, value: Any) -> None:
+        if len(self._fields):
+            assert len(self) == len(value), f"field '{name}' has length {len(value)}, expected {len(self)}"
+        self._fields[name] = value
+
+    def has(self, name: str) -> bool:
+        return name in self._fields
+
+    def get(self, name: str) -> Any:
+        return self._fields[name]
+
+    def get_fields(self) -> Dict[str, Any]:
+        return self._fields
+
+    def to(self, *args: Any, **kwargs: Any) -> "Instances":
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            if hasattr(v, "to"):
+                v = v.to(*args, **kwargs)
+            ret.set(k, v)
+        return ret
+
+    def __getitem__(self, item) -> "Instances":
+        if isinstance(item, int):
+            if item >= len(self) or item < -len(self):
+                raise IndexError("Instances index out of range!")
+            item = slice(item, None, len(self))
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v[item])
+        return ret
+
+    def __len__(self) -> int:
+        for v in self._fields.values():
+            return len(v)
+        raise NotImplementedError("Empty Instances does not support __len__!")
+
+    @staticmethod
+    def cat(instance_lists: List["Instances"]) -> "Instances":
+        assert len(instance_lists) > 0
+        if len(instance_lists) == 1:
+            return instance_lists[0]
+        ret = Instances(instance_lists[0].image_size)
+        for k in instance_lists[0]._fields.keys():
+            values = [i.get(k) for i in instance_lists]
+            v0 = values[0]
+            if isinstance(v0, torch.Tensor):
+                values = torch.cat(values, dim=0)
+            elif hasattr(type(v0), "cat"):
+                values = type(v0).cat(values)
+            else:
+                raise ValueError(f"Unsupported type {type(v0)} for concatenation")
+            ret.set(k, values)
+        return ret
+
+    def __repr__(self) -> str:
+        s = self.__class__.__name__ + "("
+        s += "num_instances={}, ".format(len(self) if self._fields else 0)
+        s += "image_height={}, image_width={}, ".format(self._image_size[0], self._image_size[1])
+        s += "fields=[{}])".format(", ".join(f"{k}: {v}" for k, v in self._fields.items()))
+        return s
+
+
+class ImageList:
+    """A batch tensor plus each image's (h, w) before padding."""
+
+    def __init__(self, tensor: torch.Tensor, image_sizes: List[Tuple[int, int]]):
+        self.tensor = tensor
+        self.image_sizes = image_sizes
+
+    def __len__(self) -> int:
+        return len(self.image_sizes)
+
+    @property
+    def device(self):
+        return self.tensor.device
