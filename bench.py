@@ -1,0 +1,181 @@
+"""Headline benchmark: images/sec of YOLOv3-416 inference including head decode + NMS on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (fused stem -> Darknet-53 -> FPN -> heads -> decode -> batched NMS
+-> top-100 gather) over one resident batch of 64 synthetic uint8 images per GPU.  Images shard across
+GPUs with no data-path collective (weak scaling); the only collectives are the barriers and the MAX over
+ranks of the timed region.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 64
+SIZE = 416
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak for bf16 on MI355X
+
+
+def _dist_setup(n_gpus: int):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local if world > 1 else 0)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    return world, rank, local
+
+
+def _barrier(world: int):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _dominant_kernel_roofline(eng, plan, convs, reps: int = 3):
+    """Time every launch of the dominant kernel (the 128x128-tile bf16 implicit-GEMM instance, used by
+    all convolutions with Cin % 64 == 0 and Cout > 64) with HIP events on the launch stream and
+    divide its algorithmic FLOPs by the time."""
+    stream = torch.cuda.current_stream()
+    flops = 0.0
+    ms = 0.0
+    launches = 0
+    for meta, step in zip(plan.meta, plan.steps):
+        c = convs[meta["name"]]
+        if c.out_channels <= 64 or c.in_channels % 64 != 0:
+            continue
+        up = 2 if meta["up"] else 1
+        fl = 2.0 * plan.N * (meta["y"].H // up) * (meta["y"].W // up) * c.out_channels * c.in_channels * c.kernel_size ** 2
+        step()  # warm
+        t = 0.0
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            step()
+            b.record(stream)
+            b.synchronize()
+            t += a.elapsed_time(b)
+        ms += t / reps
+        flops += fl
+        launches += 1
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                kernel="conv_igemm_kernel<bf16,128,128,2,2,false>", launches_per_step=launches,
+                avg_launch_us=round(ms * 1e3 / launches, 2), flop_per_launch=round(flops / launches / 1e9, 3))
+
+
+def _cpu_baseline(model, cfg, n_images: int = 8, reps: int = 2):
+    """The CPU oracle (plain torch fp32 restatement of the reference + C NMS) on a bounded sample of the
+    same workload, timed on this box's host cores."""
+    import workload
+    from oracle import nms_c, yolo_ref as R
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    imgs = [im.float() for im in workload.synthetic_images(n_images, SIZE, SIZE, seed=1)]
+    kw = dict(num_classes=cfg.MODEL.YOLOV3.NUM_CLASSES, score_thr=cfg.MODEL.YOLOV3.TEST_SCORE_THRESH,
+              nms_thr=cfg.MODEL.YOLOV3.TEST_NMS_THRESH, nms_fn=nms_c.nms, device_kind="gpu")
+    with torch.no_grad():
+        R.inference(imgs[:2], sd, **kw)  # warm-up (thread pool, allocator)
+        t0 = time.time()
+        for _ in range(reps):
+            R.inference(imgs, sd, **kw)
+        dt = time.time() - t0
+    return dict(value=round(n_images * reps / dt, 2), unit="images/sec", cores=cores, kind="port",
+                sample=f"{reps} x batch {n_images} of the same 416x416 workload, torch {torch.__version__} fp32 CPU ops + C NMS")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
+    world, rank, local = _dist_setup(args.gpus)
+    import workload
+
+    model, cfg = workload.calibrated_model(size=SIZE, calib_batch=4, config="yolov3-aug.yaml", dtype="bf16",
+                                           head_dtype="f32", device=f"cuda:{torch.cuda.current_device()}")
+    eng = model.backbone.engine()
+    # every rank gets its own shard of images (different seeds), already resident in HBM
+    imgs = workload.synthetic_images(BATCH, SIZE, SIZE, seed=1 + rank, device=model.device)
+    mean, std = cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD
+    thr, nms_thr = cfg.MODEL.YOLOV3.TEST_SCORE_THRESH, cfg.MODEL.YOLOV3.TEST_NMS_THRESH
+
+    def step():
+        return eng.detect(imgs, score_thr=thr, nms_thr=nms_thr, mean=mean, std=std, max_det=100)
+
+    for _ in range(args.warmup):
+        det, n_det = step()
+    _barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        det, n_det = step()
+    _barrier(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    plan = eng.plan(BATCH, SIZE, SIZE)
+    out = None
+    if rank == 0:
+        convs = dict(model.backbone.darknet_modules())
+        roof = _dominant_kernel_roofline(eng, plan, convs)
+        n_cand = int(plan.cand.img_offsets[BATCH].item())
+        out = {
+            "metric": "images/sec YOLOv3-416 inference incl. decode+NMS",
+            "value": round(world * BATCH * args.steps / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "YOLOv3-416 (Darknet-53 + FPN, 80 classes) batch-64 bf16 inference on one MI355X: "
+                            "preprocess + backbone + neck + heads + decode + batched NMS + top-100",
+                "batch_per_gpu": BATCH, "global_batch": BATCH * world, "input": [SIZE, SIZE],
+                "score_thresh": thr, "nms_thresh": nms_thr, "parallelism": f"image-sharded x{world}, no collective",
+                "weights": "random init (reference initialisers), BatchNorm statistics calibrated on the synthetic images",
+                "candidates_per_batch": n_cand, "detections_per_batch": int(n_det.sum().item()),
+                "conv_gflop_per_image": round(plan.flops / BATCH / 1e9, 3),
+                "conv_tflops_end_to_end": round(plan.flops * world * args.steps / elapsed / 1e12, 1),
+            },
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = _cpu_baseline(model, cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
