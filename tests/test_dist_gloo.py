@@ -1,0 +1,63 @@
+"""Multi-process (gloo, world_size 2) test of the image-sharding helpers the multi-GPU benchmark uses:
+disjoint balanced shards, MAX-over-ranks timing, ragged gather of per-image counts.  The data path itself
+has no collective (inference shards by image)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from yolo_amd.utils import dist as D
+    w, r, _ = D.init_from_env("gloo")
+    assert (w, r) == (world, rank)
+    b, e = D.shard_range(n_items, r, w)
+    # each rank "detects" on its shard: count = image index + 1
+    counts = torch.arange(b, e, dtype=torch.int32) + 1
+    D.barrier()
+    slowest = D.max_over_ranks(1.0 + rank)
+    gathered = D.gather_counts(counts)
+    if rank == 0:
+        out.put((slowest, [g.tolist() for g in gathered], (b, e)))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_items = 7
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    slowest, gathered, shard0 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert slowest == 2.0
+    assert shard0 == (0, 4)
+    assert gathered == [[1, 2, 3, 4], [5, 6, 7]]  # disjoint, complete, ordered
+
+
+def test_shard_range_properties():
+    from yolo_amd.utils.dist import shard_range
+    for n in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1

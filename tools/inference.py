@@ -1,0 +1,118 @@
+"""Inference entry point with the reference's flags and ``Predictor`` semantics
+(reference tools/inference.py:23-45,92-131), running on MI355X.
+
+    python tools/inference.py --config-file configs/yolov3.yaml --input img1.jpg img2.jpg \
+        --score-confs 0.5 --iou-thresh 0.4 --output ./output --opts MODEL.WEIGHTS yolov3.weights
+
+Differences from the reference, all at the edges of the hot path: images are read with PIL instead of
+OpenCV, and instead of opening a GUI window (cv2.imshow) the detections of every image are printed and
+written to <output>/<image name>.json.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import yolo_amd  # noqa: E402,F401
+from yolo_amd.checkpoint import YOLOV3Checkpointer  # noqa: E402
+from yolo_amd.config import get_cfg  # noqa: E402
+from yolo_amd.modeling import build_model  # noqa: E402
+
+
+def resize_shortest_edge(image: np.ndarray, short: int, max_size: int) -> np.ndarray:
+    """detectron2 ResizeShortestEdge([short, short], max_size) on an HWC uint8 image: scale so that the
+    shorter side equals ``short``, cap the longer side at ``max_size``, round to integers, bilinear."""
+    from PIL import Image
+    h, w = image.shape[:2]
+    scale = short * 1.0 / min(h, w)
+    newh, neww = (short, scale * w) if h < w else (scale * h, short)
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    neww, newh = int(neww + 0.5), int(newh + 0.5)
+    return np.asarray(Image.fromarray(image).resize((neww, newh), Image.BILINEAR))
+
+
+class Predictor:
+    """model.eval() + checkpoint load + shortest-edge resize + BGR->RGB flip + CHW float tensor, one image
+    per call (reference tools/inference.py:23-45)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.model = build_model(cfg)
+        self.model.eval()
+        YOLOV3Checkpointer(self.model).load(cfg.MODEL.WEIGHTS)
+        self.min_size, self.max_size = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST
+        self.input_format = cfg.INPUT.FORMAT
+        assert self.input_format in ["RGB", "BGR"], self.input_format
+
+    @torch.no_grad()
+    def __call__(self, original_image: np.ndarray):
+        """original_image: HWC uint8 in BGR order (OpenCV convention)."""
+        if self.input_format == "RGB":
+            original_image = original_image[:, :, ::-1]
+        height, width = original_image.shape[:2]
+        image = resize_shortest_edge(np.ascontiguousarray(original_image), self.min_size, self.max_size)
+        image = torch.as_tensor(image.astype("float32").transpose(2, 0, 1))
+        return self.model([dict(height=height, width=width, image=image)])[0]
+
+
+def read_image_bgr(path: str) -> np.ndarray:
+    from PIL import Image
+    if path.endswith(".npy"):
+        return np.load(path)
+    return np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
+
+
+def setup(args):
+    cfg = get_cfg()
+    cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(args.opts)
+    cfg.MODEL.YOLOV3.TEST_SCORE_THRESH = args.score_confs  # the CLI defaults override the YAML, as in
+    cfg.MODEL.YOLOV3.TEST_NMS_THRESH = args.iou_thresh      # the reference (tools/inference.py:96-97)
+    cfg.freeze()
+    return cfg
+
+
+def get_parser():
+    parser = argparse.ArgumentParser(description="YOLO V3 Inference")
+    parser.add_argument("--config-file", metavar="FILE", default="configs/yolov3.yaml")
+    parser.add_argument("--input", nargs="+", required=True)
+    parser.add_argument("--output", default="./output")
+    parser.add_argument("--score-confs", type=float, default=0.5)
+    parser.add_argument("--iou-thresh", type=float, default=0.4)
+    parser.add_argument("--opts", default=None, nargs=argparse.REMAINDER)
+    return parser
+
+
+def main():
+    args = get_parser().parse_args()
+    cfg = setup(args)
+    predictor = Predictor(cfg)
+    if len(args.input) == 1:
+        args.input = glob.glob(os.path.expanduser(args.input[0]))
+        assert args.input, "The input path(s) was not found"
+    if args.output:
+        os.makedirs(args.output, exist_ok=True)
+    for path in args.input:
+        predictions = predictor(read_image_bgr(path))
+        inst = predictions["instances"].to("cpu")
+        print(path, inst)
+        if args.output:
+            rec = dict(image=path, height=inst.image_size[0], width=inst.image_size[1],
+                       boxes=inst.pred_boxes.tensor.tolist(), scores=inst.scores.tolist(),
+                       classes=inst.pred_classes.tolist())
+            with open(os.path.join(args.output, os.path.basename(path) + ".json"), "w") as f:
+                json.dump(rec, f)
+
+
+if __name__ == "__main__":
+    main()

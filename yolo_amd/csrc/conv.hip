@@ -11,6 +11,8 @@
 // operand) and activations (MFMA B operand) share one loader and one fragment-read pattern.  With
 // channels on the MFMA row index each lane ends up holding 4 consecutive channels of one pixel,
 // which is what an NHWC epilogue wants.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace yolo {
@@ -40,6 +42,7 @@ struct ConvParams {
     float slope;
     int upsample;
     int y_f32;  // output element type is f32 (else bf16)
+    int dbg_noloads;
 };
 
 constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
@@ -146,24 +149,33 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // All fragment reads of a k-step (2 sub-steps of 32 k) are issued up front; the second half lands
+    // while the matrix cores work on the first.
     auto compute = [&](const char* buf) {
+        if constexpr (BF) {
+            bf16x8 a[2][FC], b[2][FP];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ko = kk ? ko1 : ko0;
-            if constexpr (BF) {
-                bf16x8 a[FC], b[FP];
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ko = kk ? ko1 : ko0;
 #pragma unroll
-                for (int i = 0; i < FC; ++i) a[i] = *(const bf16x8*)(buf + a_base + i * 16 * ROWB + ko);
+                for (int i = 0; i < FC; ++i) a[kk][i] = *(const bf16x8*)(buf + a_base + i * 16 * ROWB + ko);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) b[j] = *(const bf16x8*)(buf + b_base + j * 16 * ROWB + ko);
+                for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(buf + b_base + j * 16 * ROWB + ko);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMA block
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < FC; ++i)
 #pragma unroll
                     for (int j = 0; j < FP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            } else {
-                // f32 MFMA 16x16x4 takes ONE k per lane group; element e of each lane's 16-byte
-                // chunk feeds MFMA e, the same k permutation on both operands.
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        } else {
+            // f32 MFMA 16x16x4 takes ONE k per lane group; element e of each lane's 16-byte chunk feeds
+            // MFMA e, the same k permutation on both operands.
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ko = kk ? ko1 : ko0;
                 f32x4 a[FC], b[FP];
 #pragma unroll
                 for (int i = 0; i < FC; ++i) a[i] = *(const f32x4*)(buf + a_base + i * 16 * ROWB + ko);
@@ -185,7 +197,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     for (int s = 0; s < p.nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < p.nsteps) stage(smem + ((s + 1) & 1) * BUF);
+        if (s + 1 < p.nsteps && !p.dbg_noloads) stage(smem + ((s + 1) & 1) * BUF);
         compute(smem + (s & 1) * BUF);
     }
     __syncthreads();
@@ -285,15 +297,28 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     return YOLO_OK;
 }
 
+// Pixel-tile choice: two workgroups share a CU, so a launch runs in rounds of 512 tiles; pick the pixel
+// tile (96 or 128) that needs the least total tile-time (rounds x pixels per tile).
+static int pick_tp(int M, int n_ctiles) {
+    const long long slots = 512;
+    auto cost = [&](int tp) {
+        const long long tiles = (long long)((M + tp - 1) / tp) * n_ctiles;
+        return ((tiles + slots - 1) / slots) * tp;
+    };
+    return cost(96) < cost(128) ? 96 : 128;
+}
+
 template <typename T, bool TAP2>
 static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream) {
-    constexpr int TP = 128;
-    p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + tc - 1) / tc;
+    const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles) : 128;
+    p.n_ptiles = (p.M + tp - 1) / tp;
     switch (tc) {
-        case 128: return launch_conv<T, 128, TP, 2, 2, TAP2>(p, stream);
-        case 64: return launch_conv<T, 64, TP, 2, 2, TAP2>(p, stream);
-        default: return launch_conv<T, 32, TP, 1, 4, TAP2>(p, stream);
+        case 128:
+            if (tp == 96) return launch_conv<T, 128, 96, 2, 2, TAP2>(p, stream);
+            return launch_conv<T, 128, 128, 2, 2, TAP2>(p, stream);
+        case 64: return launch_conv<T, 64, 128, 2, 2, TAP2>(p, stream);
+        default: return launch_conv<T, 32, 128, 1, 4, TAP2>(p, stream);
     }
 }
 
@@ -378,6 +403,7 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
     p.slope = leaky_slope;
     p.upsample = upsample2x ? 1 : 0;
     p.y_f32 = y_dtype == YOLO_F32;
+    p.dbg_noloads = getenv("YOLO_DBG_NOLOADS") != nullptr;
 
     const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     hipStream_t st = (hipStream_t)stream;
