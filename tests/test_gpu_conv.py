@@ -174,3 +174,34 @@ def test_conv_rejects_bad_arguments(cuda):
     x2 = ops.alloc_view(1, 4, 4, 48, 1, torch.bfloat16, cuda)
     with pytest.raises(YoloHipError, match="Cin"):
         ops.conv2d_fwd(x2, w, b, y, cin=48, cout=64, k=1, stride=1)
+
+
+# (Cin, Cout, H, W): small images use whole-row patches, wide ones 2-D blocks; 32 channels = single slice
+PATCH_SHAPES = [(32, 64, 24, 208), (64, 128, 20, 104), (128, 256, 13, 52), (256, 512, 26, 26), (512, 1024, 13, 13),
+                (64, 64, 7, 5), (128, 128, 40, 136)]
+
+
+@pytest.mark.parametrize("shape", PATCH_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3_patch_kernel(cuda, shape):
+    """Opt-in LDS-resident-patch kernel (yolo_conv3x3_patch_fwd) against the same torch reference, with a
+    residual, incl. pixel tiles that span image rows and images, 2-D block tiles and ragged edges."""
+    from yolo_amd import ops
+    cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(cin * 7 + W)
+    N = 3
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    norm = _rand_norm(cout, g)
+    res = torch.randn(N, cout, H, W, generator=g)
+    wf, bf = ops.fold_norm(w, None, norm)
+    ref = _ref_conv(x.bfloat16().float(), wf.bfloat16().float(), None, bf, 1, 0.1, res.bfloat16().float())
+    wp, bp = ops.pack_conv(wf, bf, torch.bfloat16, cuda, patch_layout=True)
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    rv = ops.view_from_nchw(res.to(cuda), 1, torch.bfloat16)
+    yv = ops.alloc_view(N, H, W, cout, 1, torch.bfloat16, cuda)
+    ops.conv3x3_patch_fwd(xv, wp, bp, yv, cin=cin, cout=cout, residual=rv)
+    torch.cuda.synchronize()
+    got = yv.nchw().float().cpu()
+    assert _rel_err(got, ref) < BF16_TOL
+    assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, -1].abs().max()) == 0.0

@@ -42,7 +42,6 @@ struct ConvParams {
     float slope;
     int upsample;
     int y_f32;  // output element type is f32 (else bf16)
-    int dbg_noloads;
 };
 
 constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
@@ -197,7 +196,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     for (int s = 0; s < p.nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < p.nsteps && !p.dbg_noloads) stage(smem + ((s + 1) & 1) * BUF);
+        if (s + 1 < p.nsteps) stage(smem + ((s + 1) & 1) * BUF);
         compute(smem + (s & 1) * BUF);
     }
     __syncthreads();
@@ -403,7 +402,6 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
     p.slope = leaky_slope;
     p.upsample = upsample2x ? 1 : 0;
     p.y_f32 = y_dtype == YOLO_F32;
-    p.dbg_noloads = getenv("YOLO_DBG_NOLOADS") != nullptr;
 
     const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     hipStream_t st = (hipStream_t)stream;
