@@ -107,6 +107,22 @@ int yolo_stem_fwd(const void* img, int img_dtype, int N, int Hs, int Ws,
                   const float* w, const float* bias, const yolo_view* y, int Cout,
                   float leaky_slope, int y_dtype, void* stream);
 
+/*
+ * yolo_stem_fwd followed by the first down-sampling conv, in one launch, bf16.  Replaces the same call
+ * sites as yolo_stem_fwd plus ResidualBlock.downsample of `res1` (darknet.py:113-116: Conv2d 3x3/s2 +
+ * BN + leaky_relu); the stem's 32-channel full-resolution output stays in LDS and is never written.
+ *   img .. b_stem   as for yolo_stem_fwd (stem Cout == 32)
+ *   w_down_packed   the bf16 packing yolo_conv2d_fwd takes for Cin == 32, k == 3:
+ *                   [Cout_pad][10][32] (9 taps + one zero tap), Cout == 64; b_down [>= 64] f32
+ *   H, W            padded network input size (even; stem output size); pixels beyond Hs, Ws are zero
+ *   y               bf16 output view, H/2 x W/2, 64 channels
+ */
+int yolo_stem_down_fwd(const void* img, int img_dtype, int N, int Hs, int Ws,
+                       const float* mean_host, const float* std_host,
+                       const float* w_stem, const float* b_stem,
+                       const void* w_down_packed, const float* b_down,
+                       const yolo_view* y, int H, int W, float leaky_slope, void* stream);
+
 /* Nearest-neighbour 2x upsample of an NHWC view into another (channel slice of a) view.
  * Replaces nn.Upsample(scale_factor=2, mode="nearest") + torch.cat at fpn.py:31,36,179 for
  * callers that do not use yolo_conv2d_fwd's fused form.  C % 8 == 0 (bf16) / % 4 (f32). */

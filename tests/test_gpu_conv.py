@@ -205,3 +205,48 @@ def test_conv3x3_patch_kernel(cuda, shape):
     assert _rel_err(got, ref) < BF16_TOL
     assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
     assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, -1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("img_dtype", [torch.float32, torch.uint8], ids=["f32img", "u8img"])
+@pytest.mark.parametrize("geom", [(2, 50, 75, 64, 96), (3, 96, 160, 96, 160), (1, 33, 47, 64, 64)],
+                         ids=lambda g_: "x".join(map(str, g_)))
+def test_stem_down_fused(cuda, geom, img_dtype):
+    """yolo_stem_down_fwd = preprocess + BasicStem (darknet.py:57-60) + res1.downsample (darknet.py:113-116),
+    against torch fp32 ops on bf16-rounded weights and a bf16-rounded stem output (what the two separate
+    bf16 launches compute), and bit-for-bit-close against those two launches themselves."""
+    from yolo_amd import ops
+    g = torch.Generator().manual_seed(13)
+    N, Hs, Ws, H, W = geom
+    img = torch.randint(0, 256, (N, 3, Hs, Ws), generator=g)
+    w0 = torch.randn(32, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    n0 = _rand_norm(32, g)
+    w1 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    n1 = _rand_norm(64, g)
+    mean, std = (10.0, 20.0, 30.0), (255.0, 128.0, 64.0)
+    xin = torch.zeros(N, 3, H, W)
+    xin[:, :, :Hs, :Ws] = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    wf0, bf0 = ops.fold_norm(w0, None, n0)
+    wf1, bf1 = ops.fold_norm(w1, None, n1)
+    s = _ref_conv(xin.bfloat16().float(), wf0.bfloat16().float(), None, bf0, 1, 0.1, None).bfloat16().float()
+    ref = _ref_conv(s, wf1.bfloat16().float(), None, bf1, 2, 0.1, None)
+
+    ws, bs = ops.pack_stem(wf0, bf0, cuda)
+    wd, bd = ops.pack_conv(wf1, bf1, torch.bfloat16, cuda)
+    dimg = img.to(img_dtype).to(cuda).contiguous()
+    yv = ops.alloc_view(N, H // 2, W // 2, 64, 1, torch.bfloat16, cuda)
+    ops.stem_down_fwd(dimg, ws, bs, wd, bd, yv, padded_hw=(H, W), mean=mean, std=std)
+    torch.cuda.synchronize()
+    got = yv.nchw().float().cpu()
+    assert _rel_err(got, ref) < BF16_TOL
+    assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, -1].abs().max()) == 0.0
+
+    sv = ops.alloc_view(N, H, W, 32, 1, torch.bfloat16, cuda)
+    y2 = ops.alloc_view(N, H // 2, W // 2, 64, 1, torch.bfloat16, cuda)
+    ops.stem_fwd(dimg, ws, bs, sv, mean=mean, std=std)
+    ops.conv2d_fwd(sv, wd, bd, y2, cin=32, cout=64, k=3, stride=2)
+    torch.cuda.synchronize()
+    two = y2.nchw().float().cpu()
+    # same bf16 stem values, fp32 accumulation in a different order: at most one bf16 ulp apart
+    assert float((got - two).abs().max() / two.abs().max()) < 2 ** -7
+    assert float((got != two).float().mean()) < 0.05

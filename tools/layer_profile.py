@@ -34,10 +34,18 @@ def main():
 
     stem = eng._packed["bottom_up.stem.conv"]
     from yolo_amd import ops
-    t = timeit(lambda: ops.stem_fwd(imgs, stem.w, stem.b, P.stem_out, mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD))
-    fl = 2 * N * size * size * 32 * 27
-    by = N * size * size * (3 + 32 * 2)
-    rows.append(("stem", 3, 32, 3, 1, size, t, fl, by))
+    if P.stem_fused_y is not None:
+        d = eng._packed["bottom_up.res1.0.downsample"]
+        t = timeit(lambda: ops.stem_down_fwd(imgs, stem.w, stem.b, d.w, d.b, P.stem_fused_y, padded_hw=(size, size),
+                                             mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD))
+        fl = 2 * N * size * size * 32 * 27 + 2 * N * (size // 2) ** 2 * 64 * 32 * 9
+        by = N * size * size * 3 + N * (size // 2) ** 2 * 64 * 2
+        rows.append(("stem+res1.0.downsample (fused)", 3, 64, 3, 2, size, t, fl, by))
+    else:
+        t = timeit(lambda: ops.stem_fwd(imgs, stem.w, stem.b, P.stem_out, mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD))
+        fl = 2 * N * size * size * 32 * 27
+        by = N * size * size * (3 + 32 * 2)
+        rows.append(("stem", 3, 32, 3, 1, size, t, fl, by))
     for meta, step in zip(P.meta, P.steps):
         c = convs[meta["name"]]
         y = meta["y"]

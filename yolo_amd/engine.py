@@ -39,7 +39,8 @@ class Plan:
     H: int
     W: int
     steps: List[Callable[[], None]] = field(default_factory=list)
-    stem_out: Optional[View] = None
+    stem_out: Optional[View] = None   # None when the stem is fused into the first down-sampling conv
+    stem_fused_y: Optional[View] = None  # output of the fused stem + res1.downsample launch
     heads: List[View] = field(default_factory=list)  # p3, p4, p5
     taps: Dict[str, View] = field(default_factory=dict)
     cand: Optional[ops.Candidates] = None
@@ -56,7 +57,7 @@ class Yolov3Engine:
 
     def __init__(self, backbone, *, num_classes: int, anchors_wh, strides: Sequence[int] = (8, 16, 32),
                  dtype: torch.dtype = torch.bfloat16, head_dtype: torch.dtype = torch.float32,
-                 blocks: Sequence[int] = (1, 2, 8, 8, 4)):
+                 blocks: Sequence[int] = (1, 2, 8, 8, 4), fuse_stem: bool = True):
         self.backbone = backbone
         self.num_classes = num_classes
         self.num_anchors = len(anchors_wh[0])
@@ -65,6 +66,7 @@ class Yolov3Engine:
         self.dtype = dtype
         self.head_dtype = head_dtype
         self.blocks = list(blocks)
+        self.fuse_stem = fuse_stem
         self.device = next(backbone.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("Yolov3Engine needs the model on an MI355X (cuda device); there is no CPU path")
@@ -107,7 +109,12 @@ class Yolov3Engine:
                                                   slope=slope, residual=residual, upsample2x=up))
 
         stem = pk["bottom_up.stem.conv"]
-        P.stem_out = ops.alloc_view(N, H, W, stem.cout, 1, dt, dev)
+        down0 = pk["bottom_up.res1.0.downsample"]
+        # bf16: stem and the first stride-2 conv run as one launch, the stem output never reaches HBM
+        fused = (self.fuse_stem and dt == torch.bfloat16 and stem.cout == 32 and down0.cout == 64
+                 and down0.k == 3 and down0.stride == 2)
+        if not fused:
+            P.stem_out = ops.alloc_view(N, H, W, stem.cout, 1, dt, dev)
         P.flops += 2 * N * H * W * stem.cout * 27
         x = P.stem_out
         h, w, c_in = H, W, stem.cout
@@ -124,7 +131,11 @@ class Yolov3Engine:
             co = chans[si - 1]
             X = ops.alloc_view(N, h, w, co, 1, dt, dev)
             T = ops.alloc_view(N, h, w, co // 2, 1, dt, dev)
-            conv(f"bottom_up.res{si}.0.downsample", x, X)
+            if si == 1 and fused:
+                P.stem_fused_y = X
+                P.flops += 2 * N * h * w * down0.cout * down0.cin * 9
+            else:
+                conv(f"bottom_up.res{si}.0.downsample", x, X)
             for b in range(nb):
                 p = f"bottom_up.res{si}.{b}"
                 conv(p + ".conv1", X, T)
@@ -175,7 +186,12 @@ class Yolov3Engine:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         P = self.plan(N, padded_hw[0], padded_hw[1])
         stem = self._packed["bottom_up.stem.conv"]
-        ops.stem_fwd(images.contiguous(), stem.w, stem.b, P.stem_out, mean=mean, std=std)
+        if P.stem_fused_y is not None:
+            d = self._packed["bottom_up.res1.0.downsample"]
+            ops.stem_down_fwd(images.contiguous(), stem.w, stem.b, d.w, d.b, P.stem_fused_y,
+                              padded_hw=(P.H, P.W), mean=mean, std=std)
+        else:
+            ops.stem_fwd(images.contiguous(), stem.w, stem.b, P.stem_out, mean=mean, std=std)
         for step in P.steps:
             step()
         return P

@@ -192,6 +192,29 @@ def stem_fwd(images: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: View,
     check(code, "yolo_stem_fwd")
 
 
+def stem_down_fwd(images: torch.Tensor, w_stem: torch.Tensor, b_stem: torch.Tensor, w_down: torch.Tensor,
+                  b_down: torch.Tensor, y: View, *, padded_hw: Tuple[int, int], mean: Sequence[float],
+                  std: Sequence[float], slope: float = 0.1) -> None:
+    """Stem + first stride-2 conv in one launch (bf16).  ``w_down``/``b_down`` from pack_conv(bf16), Cin 32."""
+    _require_cuda(images, "stem_down_fwd")
+    assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    assert y.buf.dtype == torch.bfloat16 and w_down.dtype == torch.bfloat16 and w_down.shape[1] == 320
+    if images.dtype == torch.float32:
+        code_dt = 0
+    elif images.dtype == torch.uint8:
+        code_dt = 1
+    else:
+        raise ValueError(f"stem_down_fwd: image dtype {images.dtype}")
+    N, _, Hs, Ws = images.shape
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    yv = y.c()
+    code = lib().yolo_stem_down_fwd(_ptr(images), code_dt, N, Hs, Ws, m, s, _ptr(w_stem), _ptr(b_stem),
+                                    _ptr(w_down), _ptr(b_down), ctypes.byref(yv), int(padded_hw[0]),
+                                    int(padded_hw[1]), float(slope), _stream())
+    check(code, "yolo_stem_down_fwd")
+
+
 def upsample2x(x: View, y: View) -> None:
     _require_cuda(x.buf, "upsample2x")
     xv, yv = x.c(), y.c()
