@@ -67,7 +67,7 @@ typedef struct yolo_view {
  *   residual NULL, or a view with y's geometry (its own ptr / ch_total / ch_offset / halo)
  *   y        output view with H, W = conv output size (2x that when upsample2x)
  *   k in {1,3}; stride in {1,2}; pad = (k-1)/2
- *   leaky_slope: negative-side slope; 1.0f = linear (no activation)
+ *   leaky_slope: negative-side slope in [0, 1]; 1.0f = linear (no activation)
  *   dtype    element type of x, w_packed, residual (YOLO_F32 / YOLO_BF16); accumulation is f32
  *   y_dtype  element type of y
  */

@@ -11,6 +11,8 @@ namespace yolo {
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -58,8 +60,23 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     bf16_t h = (bf16_t)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
     return __builtin_bit_cast(unsigned short, h);
 }
+// one v_cvt_pk_bf16_f32: both values rounded to nearest even, lo in bits 0..15
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+
+// LeakyReLU for a negative-side slope in [0, 1]: max(x, slope * x) is bit-identical to
+// x >= 0 ? x : slope * x there (slope 1 = linear), and costs a packed multiply + one max per element
+// instead of multiply + compare + select.  Raw v_max_f32 skips the compiler's NaN-canonicalising extra max.
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x4 leaky4(f32x4 v, float slope) {
+    const f32x4 m = v * slope;
+    return f32x4{vmax_raw(v[0], m[0]), vmax_raw(v[1], m[1]), vmax_raw(v[2], m[2]), vmax_raw(v[3], m[3])};
 }
 
 }  // namespace yolo

@@ -142,11 +142,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const int ko0 = (q ^ l7) << 4;                               // k chunk q, swizzled
     const int ko1 = ko0 ^ 64;                                    // k chunk 4+q
 
+    // accumulators start from the bias (lane holds channels ch0 + 16*i + 0..3 of pixel column l15)
     f32x4 acc[FC][FP];
 #pragma unroll
-    for (int i = 0; i < FC; ++i)
+    for (int i = 0; i < FC; ++i) {
+        const f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + wc * (TC / WC) + q * 4 + i * 16);
 #pragma unroll
-        for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FP; ++j) acc[i][j] = bv;
+    }
 
     // All fragment reads of a k-step (2 sub-steps of 32 k) are issued up front; the second half lands
     // while the matrix cores work on the first.
@@ -201,7 +204,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
 
-    // ---- epilogue 1: bias + LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte
+    // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte
     //      chunks XOR-swizzled by (pixel & 7)
     {
         const int ch0 = wc * (TC / WC) + q * 4;
@@ -209,13 +212,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             const int ch = ch0 + i * 16;
-            const f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + ch);
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 const int px = px0 + j * 16;
-                f32x4 v = acc[i][j] + bv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
+                const f32x4 v = leaky4(acc[i][j], p.slope);
                 *(f32x4*)(smem + px * (TC * 4) + (((ch >> 2) ^ (px & 7)) << 4)) = v;
             }
         }
@@ -336,6 +336,7 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
     YOLO_REQUIRE(k == 1 || k == 3, "conv2d: kernel size %d (1 or 3)", k);
     YOLO_REQUIRE(stride == 1 || stride == 2, "conv2d: stride %d (1 or 2)", stride);
     YOLO_REQUIRE(N > 0 && Cin > 0 && Cout > 0, "conv2d: N/Cin/Cout must be positive");
+    YOLO_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, "conv2d: leaky slope %g outside [0, 1]", (double)leaky_slope);
     const int pad = (k - 1) / 2;
     const int es = (int)elem_size(dtype), yes = (int)elem_size(y_dtype);
     const bool tap2 = dtype == YOLO_BF16 && Cin == 32 && k == 3;

@@ -194,11 +194,9 @@ __global__ void __launch_bounds__(256, 2) stem_down_kernel(const StemDownParams 
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sfrag[0][s], b, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sfrag[1][s], b, acc1, 0, 0, 0);
             }
-            u32x4 pk;
-            pk[0] = pack_bf16x2(fmaxf(acc0[0], acc0[0] * p.slope), fmaxf(acc0[1], acc0[1] * p.slope));
-            pk[1] = pack_bf16x2(fmaxf(acc0[2], acc0[2] * p.slope), fmaxf(acc0[3], acc0[3] * p.slope));
-            pk[2] = pack_bf16x2(fmaxf(acc1[0], acc1[0] * p.slope), fmaxf(acc1[1], acc1[1] * p.slope));
-            pk[3] = pack_bf16x2(fmaxf(acc1[2], acc1[2] * p.slope), fmaxf(acc1[3], acc1[3] * p.slope));
+            const f32x4 l0 = leaky4(acc0, p.slope), l1 = leaky4(acc1, p.slope);
+            u32x4 pk = {pack_bf16x2(l0[0], l0[1]), pack_bf16x2(l0[2], l0[3]), pack_bf16x2(l1[0], l1[1]),
+                        pack_bf16x2(l1[2], l1[3])};
             if (border) {
                 const int sy = 2 * oy0 - 1 + py, sx = 2 * ox0 - 1 + px;
                 if (!(sy >= 0 && sy < p.Hst && sx >= 0 && sx < p.Wst)) pk = u32x4{0u, 0u, 0u, 0u};
@@ -241,12 +239,9 @@ __global__ void __launch_bounds__(256, 2) stem_down_kernel(const StemDownParams 
                 char* o = ybase + (oy * p.y_row_stride + ox * p.y_pix_stride + q * 16);
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    const f32x4 lo = acc[2 * pr][j], hi = acc[2 * pr + 1][j];
-                    u32x4 pk;
-                    pk[0] = pack_bf16x2(fmaxf(lo[0], lo[0] * p.slope), fmaxf(lo[1], lo[1] * p.slope));
-                    pk[1] = pack_bf16x2(fmaxf(lo[2], lo[2] * p.slope), fmaxf(lo[3], lo[3] * p.slope));
-                    pk[2] = pack_bf16x2(fmaxf(hi[0], hi[0] * p.slope), fmaxf(hi[1], hi[1] * p.slope));
-                    pk[3] = pack_bf16x2(fmaxf(hi[2], hi[2] * p.slope), fmaxf(hi[3], hi[3] * p.slope));
+                    const f32x4 lo = leaky4(acc[2 * pr][j], p.slope), hi = leaky4(acc[2 * pr + 1][j], p.slope);
+                    const u32x4 pk = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                      pack_bf16x2(hi[2], hi[3])};
                     *(u32x4*)(o + 64 * pr) = pk;
                 }
             }
