@@ -23,3 +23,10 @@ for _ in range(K): eng.run_backbone(imgs, mean, std)
 torch.cuda.synchronize()
 dt = (time.time() - t) / K
 print(f"backbone only {dt*1e3:.2f} ms  {P.flops/dt/1e12:.1f} TFLOP/s")
+t = time.time()
+for _ in range(K):
+    Pp = eng.run_backbone(imgs, mean, std)
+    eng.decode(Pp, 0.25)
+torch.cuda.synchronize()
+dt = (time.time() - t) / K
+print(f"backbone+decode (no sync) {dt*1e3:.2f} ms")

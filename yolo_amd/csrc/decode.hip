@@ -6,13 +6,15 @@
 // (:309-383) with Box2BoxTransform.apply_deltas (yolo/modeling/box_regression.py:44-64).
 //
 // Three launches for the whole batch:
-//   count : one wave per grid cell reads the cell's A*(5+C) channels once (coalesced, 4 channels per
-//           lane) and counts the (anchor, class) pairs that pass both filters;
+//   count : one lane per grid cell reads the cell's A objectness logits; cells where an anchor passes the
+//           first filter are then read whole by the wave (coalesced, 4 channels per lane) to count the
+//           (anchor, class) pairs that pass both filters;
 //   scan  : per image exclusive prefix sum of the cell counts;
 //   write : cells with a non-zero count are decoded again and their candidates written at
 //           image_base + cell_offset + rank, rank = position in (anchor, class) order -- the
 //           reference's candidate order (level, y, x, anchor, class) without atomics.
-// The head tensor is streamed once by `count`; `write` touches only cells that produced candidates.
+// `count` touches one sector per anchor of every cell plus the full rows of the few live cells; `write`
+// touches only cells that produced candidates.
 //
 // Built with -ffp-contract=off: the box arithmetic keeps the reference's rounding sequence.
 #include "common.h"
@@ -130,57 +132,79 @@ __device__ __forceinline__ void cell_conf(const DecodeParams& p, const char* cpt
         conf[a] = a < p.A ? sigmoidf_ref(load_elem<T>(cptr, a * p.K + 4)) : 0.f;  // yolo.py:413
 }
 
+// One wave per group of 64 consecutive (image, cell) slots: every lane reads the objectness logits of its own
+// cell (A small loads in flight per lane instead of one dependent round trip per cell), then the wave walks
+// only the cells where some anchor passed the first filter and counts their candidates cooperatively.
 template <typename T>
 __global__ void __launch_bounds__(256) decode_count_kernel(const DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const long long total = (long long)p.N * p.cells;
+    const long long groups = (total + 63) >> 6;
     const long long nw = (long long)gridDim.x * 4;
     const int nchunks = (p.AK + 255) >> 8;
-    for (long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += nw) {
-        const int n = (int)(w / p.cells);
-        const int cell = (int)(w - (long long)n * p.cells);
+    for (long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += nw) {
+        const long long w = g * 64 + lane;
+        const bool valid = w < total;
+        const long long wc = valid ? w : total - 1;
+        const int n = (int)(wc / p.cells);
+        const int cell = (int)(wc - (long long)n * p.cells);
         const CellPos c = locate_cell(p, n, cell);
         float conf[MAX_ANCHORS];
         cell_conf<T>(p, c.ptr, conf);
-        int cnt = 0;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            float sc[4];
-            const unsigned h = cell_hits<T>(p, c.ptr, chunk, lane, conf, sc);
+        bool any = false;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cnt += __popcll(__ballot((h >> e) & 1u));
+        for (int a = 0; a < MAX_ANCHORS; ++a) any = any || conf[a] > p.thr;
+        unsigned long long todo = __ballot(valid && any);
+        int mine = 0;
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const long long wb = g * 64 + b;  // wave-uniform
+            const int nb = (int)(wb / p.cells);
+            const CellPos cb = locate_cell(p, nb, (int)(wb - (long long)nb * p.cells));
+            float confb[MAX_ANCHORS];
+#pragma unroll
+            for (int a = 0; a < MAX_ANCHORS; ++a) confb[a] = __shfl(conf[a], b, 64);
+            int cnt = 0;
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
+                float sc[4];
+                const unsigned h = cell_hits<T>(p, cb.ptr, chunk, lane, confb, sc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cnt += __popcll(__ballot((h >> e) & 1u));
+            }
+            if (lane == b) mine = cnt;
         }
-        if (lane == 0) p.cell_count[w] = cnt;
+        if (valid) p.cell_count[w] = mine;
     }
 }
 
-// One workgroup per image: exclusive scan of the image's cell counts.
+// One workgroup per image: exclusive scan of the image's cell counts.  Each thread owns a contiguous run of
+// cells; one block-wide scan of the 256 run sums, then every thread rewrites its run.
 __global__ void __launch_bounds__(256) decode_scan_kernel(const DecodeParams p) {
     __shared__ int wsum[4];
-    __shared__ int carry_s;
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* cnt = p.cell_count + (long long)n * p.cells;
     int* off = p.cell_off + (long long)n * p.cells;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < p.cells; base += 256) {
-        const int i = base + tid;
-        const int v = i < p.cells ? cnt[i] : 0;
-        int incl = v;
+    const int per = (p.cells + 255) / 256;
+    const int lo = tid * per;
+    const int hi = lo + per < p.cells ? lo + per : p.cells;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    int incl = sum;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int pre = carry_s;
-        for (int k = 0; k < wave; ++k) pre += wsum[k];
-        if (i < p.cells) off[i] = pre + incl - v;
-        __syncthreads();
-        if (tid == 255) carry_s = pre + incl;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
     }
-    if (tid == 0) p.img_total[n] = carry_s;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int k = 0; k < wave; ++k) run += wsum[k];
+    for (int i = lo; i < hi; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 255) p.img_total[n] = run;
 }
 
 template <typename T>
@@ -208,8 +232,13 @@ __global__ void __launch_bounds__(256) decode_write_kernel(const DecodeParams p)
     const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const int* cnt = p.cell_count + (long long)n * p.cells;
     const int* off = p.cell_off + (long long)n * p.cells;
-    for (int cell = blockIdx.x * 4 + wave; cell < p.cells; cell += gridDim.x * 4) {
-        if (cnt[cell] == 0) continue;
+    for (int cg = blockIdx.x * 4 + wave; cg * 64 < p.cells; cg += gridDim.x * 4) {
+      // 64 cells per wave; only those with candidates are decoded again
+      const int mycell = cg * 64 + lane;
+      unsigned long long todo = __ballot(mycell < p.cells && cnt[mycell < p.cells ? mycell : 0] != 0);
+      while (todo) {
+        const int cell = cg * 64 + __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
         const CellPos c = locate_cell(p, n, cell);
         float conf[MAX_ANCHORS];
         cell_conf<T>(p, c.ptr, conf);
@@ -266,6 +295,7 @@ __global__ void __launch_bounds__(256) decode_write_kernel(const DecodeParams p)
             }
             pos += tot;
         }
+      }
     }
 }
 
@@ -346,10 +376,10 @@ extern "C" int yolo_decode(const yolo_view* head, int L, const int* stride_host,
     p.cap = cap;
 
     hipStream_t st = (hipStream_t)stream;
-    const long long waves = (long long)cells * N;
+    const long long waves = ((long long)cells * N + 63) / 64;
     long long cblocks = (waves + 3) / 4;
     if (cblocks > 4096) cblocks = 4096;
-    int wblocks = (cells + 3) / 4;
+    int wblocks = ((cells + 63) / 64 + 3) / 4;
     if (wblocks > 64) wblocks = 64;
     if (head_dtype == YOLO_BF16) {
         hipLaunchKernelGGL((decode_count_kernel<unsigned short>), dim3((unsigned)cblocks), dim3(256), 0, st, p);
