@@ -123,6 +123,21 @@ int yolo_stem_down_fwd(const void* img, int img_dtype, int N, int Hs, int Ws,
                        const void* w_down_packed, const float* b_down,
                        const yolo_view* y, int H, int W, float leaky_slope, void* stream);
 
+/*
+ * One whole 64-channel residual block in one launch, bf16:
+ *   y = x + leaky(conv3x3(leaky(conv1x1(x, w1) + b1), w2) + b2)
+ * Replaces ResidualBlock.forward after its down-sampling conv (darknet.py:117-126: residual = x.clone(),
+ * conv1 1x1 64 -> 32 + BN + leaky_relu, conv2 3x3 32 -> 64 + BN + leaky_relu, out += residual); the
+ * 32-channel intermediate stays in LDS.
+ *   x          bf16 view, 64 channels, halo >= 1
+ *   w1_packed  yolo_conv2d_fwd's bf16 packing of the 1x1 conv: [Cout_pad][64]; b1 [>= 32] f32
+ *   w2_packed  yolo_conv2d_fwd's bf16 packing of the 3x3 conv: [Cout_pad][10][32]; b2 [>= 64] f32
+ *   y          bf16 view of x's spatial size, 64 channels, in a buffer that does not overlap x's
+ */
+int yolo_resblock_c64_fwd(const yolo_view* x, const void* w1_packed, const float* b1,
+                          const void* w2_packed, const float* b2, const yolo_view* y,
+                          int N, float leaky_slope, void* stream);
+
 /* Nearest-neighbour 2x upsample of an NHWC view into another (channel slice of a) view.
  * Replaces nn.Upsample(scale_factor=2, mode="nearest") + torch.cat at fpn.py:31,36,179 for
  * callers that do not use yolo_conv2d_fwd's fused form.  C % 8 == 0 (bf16) / % 4 (f32). */

@@ -250,3 +250,47 @@ def test_stem_down_fused(cuda, geom, img_dtype):
     # same bf16 stem values, fp32 accumulation in a different order: at most one bf16 ulp apart
     assert float((got - two).abs().max() / two.abs().max()) < 2 ** -7
     assert float((got != two).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("geom", [(2, 24, 40), (3, 13, 21), (1, 8, 16), (2, 52, 52)], ids=lambda g_: "x".join(map(str, g_)))
+def test_resblock_c64_fused(cuda, geom):
+    """yolo_resblock_c64_fwd = ResidualBlock.forward minus the downsample (darknet.py:117-126) for C = 64, against
+    torch fp32 ops on bf16-rounded operands with a bf16-rounded intermediate, and against the two separate
+    launches; ragged tiles, image borders (zero padding of the intermediate) and the halo stay untouched."""
+    from yolo_amd import ops
+    g = torch.Generator().manual_seed(29)
+    N, H, W = geom
+    x = torch.randn(N, 64, H, W, generator=g)
+    w1 = torch.randn(32, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    w2 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    n1, n2 = _rand_norm(32, g), _rand_norm(64, g)
+    wf1, bf1 = ops.fold_norm(w1, None, n1)
+    wf2, bf2 = ops.fold_norm(w2, None, n2)
+    xq = x.bfloat16().float()
+    t = _ref_conv(xq, wf1.bfloat16().float(), None, bf1, 1, 0.1, None).bfloat16().float()
+    ref = _ref_conv(t, wf2.bfloat16().float(), None, bf2, 1, 0.1, xq)
+
+    wp1, bp1 = ops.pack_conv(wf1, bf1, torch.bfloat16, cuda)
+    wp2, bp2 = ops.pack_conv(wf2, bf2, torch.bfloat16, cuda)
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    yv = ops.alloc_view(N, H, W, 64, 1, torch.bfloat16, cuda)
+    ops.resblock_c64_fwd(xv, wp1, bp1, wp2, bp2, yv)
+    torch.cuda.synchronize()
+    got = yv.nchw().float().cpu()
+    assert _rel_err(got, ref) < BF16_TOL
+    assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, -1].abs().max()) == 0.0
+    assert float(yv.buf[:, -1].abs().max()) == 0.0 and float(yv.buf[:, :, 0].abs().max()) == 0.0
+
+    tv = ops.alloc_view(N, H, W, 32, 1, torch.bfloat16, cuda)
+    y2 = ops.alloc_view(N, H, W, 64, 1, torch.bfloat16, cuda)
+    ops.conv2d_fwd(xv, wp1, bp1, tv, cin=64, cout=32, k=1, stride=1)
+    ops.conv2d_fwd(tv, wp2, bp2, y2, cin=32, cout=64, k=3, stride=1, residual=xv)
+    torch.cuda.synchronize()
+    two = y2.nchw().float().cpu()
+    assert float((got - two).abs().max() / two.abs().max()) < 2 ** -7
+    assert float((got != two).float().mean()) < 0.05
+    # in-place use is rejected
+    from yolo_amd._lib import YoloHipError
+    with pytest.raises(YoloHipError, match="overlap"):
+        ops.resblock_c64_fwd(xv, wp1, bp1, wp2, bp2, xv)

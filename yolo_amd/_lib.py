@@ -37,6 +37,7 @@ SIGNATURES = {
                               c_int, c_float, c_int, c_void_p]),
     "yolo_stem_down_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p, c_void_p, c_void_p,
                                    c_void_p, _VP, c_int, c_int, c_float, c_void_p]),
+    "yolo_resblock_c64_fwd": (c_int, [_VP, c_void_p, c_void_p, c_void_p, c_void_p, _VP, c_int, c_float, c_void_p]),
     "yolo_upsample2x_nhwc": (c_int, [_VP, _VP, c_int, c_int, c_int, c_void_p]),
     "yolo_decode": (c_int, [_VP, c_int, _IP, _FP, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

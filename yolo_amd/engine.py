@@ -41,6 +41,7 @@ class Plan:
     steps: List[Callable[[], None]] = field(default_factory=list)
     stem_out: Optional[View] = None   # None when the stem is fused into the first down-sampling conv
     stem_fused_y: Optional[View] = None  # output of the fused stem + res1.downsample launch
+    pre_steps: List[Callable[[], None]] = field(default_factory=list)  # fused launches that run before `steps`
     heads: List[View] = field(default_factory=list)  # p3, p4, p5
     taps: Dict[str, View] = field(default_factory=dict)
     cand: Optional[ops.Candidates] = None
@@ -136,8 +137,18 @@ class Yolov3Engine:
                 P.flops += 2 * N * h * w * down0.cout * down0.cin * 9
             else:
                 conv(f"bottom_up.res{si}.0.downsample", x, X)
+            # bf16, 64 channels: each residual block is one launch (the 32-channel intermediate stays in LDS),
+            # ping-ponging between two buffers because that launch cannot run in place
+            fuse_block = (self.fuse_stem and fused and si == 1 and co == 64 and si not in cat)
+            X2 = ops.alloc_view(N, h, w, co, 1, dt, dev) if fuse_block else None
             for b in range(nb):
                 p = f"bottom_up.res{si}.{b}"
+                if fuse_block:
+                    c1, c2 = pk[p + ".conv1"], pk[p + ".conv2"]
+                    P.flops += 2 * N * h * w * (c1.cout * c1.cin + c2.cout * c2.cin * 9)
+                    P.pre_steps.append(lambda c1=c1, c2=c2, a=X, o=X2: ops.resblock_c64_fwd(a, c1.w, c1.b, c2.w, c2.b, o))
+                    X, X2 = X2, X
+                    continue
                 conv(p + ".conv1", X, T)
                 last = b == nb - 1
                 if last and si in cat:
@@ -192,6 +203,8 @@ class Yolov3Engine:
                               padded_hw=(P.H, P.W), mean=mean, std=std)
         else:
             ops.stem_fwd(images.contiguous(), stem.w, stem.b, P.stem_out, mean=mean, std=std)
+        for step in P.pre_steps:
+            step()
         for step in P.steps:
             step()
         return P

@@ -215,6 +215,17 @@ def stem_down_fwd(images: torch.Tensor, w_stem: torch.Tensor, b_stem: torch.Tens
     check(code, "yolo_stem_down_fwd")
 
 
+def resblock_c64_fwd(x: View, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, y: View, *,
+                     slope: float = 0.1) -> None:
+    """One 64-channel residual block (1x1 64->32, 3x3 32->64, + x) in one launch; y must not alias x."""
+    _require_cuda(x.buf, "resblock_c64_fwd")
+    assert x.buf.dtype == torch.bfloat16 and y.buf.dtype == torch.bfloat16
+    assert w1.dtype == torch.bfloat16 and w1.shape[1] == 64 and w2.dtype == torch.bfloat16 and w2.shape[1] == 320
+    xv, yv = x.c(), y.c()
+    check(lib().yolo_resblock_c64_fwd(ctypes.byref(xv), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), ctypes.byref(yv),
+                                      x.N, float(slope), _stream()), "yolo_resblock_c64_fwd")
+
+
 def upsample2x(x: View, y: View) -> None:
     _require_cuda(x.buf, "upsample2x")
     xv, yv = x.c(), y.c()
