@@ -79,6 +79,10 @@ int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,
 /* Rows of the packed weight buffer for Cout output channels (Cout rounded up to the channel tile). */
 int yolo_conv_cout_pad(int Cout);
 
+/* Introspection for benchmarks and profilers: the workgroup tile (output channels x output pixels) that
+ * yolo_conv2d_fwd uses for M = N*Ho*Wo output pixels and Cout channels, i.e. which kernel instance runs. */
+int yolo_conv_tile_shape(int M, int Cout, int* tile_channels, int* tile_pixels);
+
 /*
  * Alternative kernel for the 3x3 / stride-1 / bf16 case of yolo_conv2d_fwd (same reference call sites,
  * same epilogue minus the upsample): the input patch of a 128-pixel tile stays in LDS and the 9 taps are

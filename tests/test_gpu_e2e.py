@@ -158,3 +158,28 @@ def test_every_layer_bf16_teacher_forced(cuda, calibrated):
         worst = max(worst, err)
         assert err < 5e-2, (name, err)
     assert worst < 2e-2  # one bf16 ulp at the top of the range is 2^-8; typical worst layer is ~4e-3
+
+
+def test_pipelined_detect_equals_detect(cuda, calibrated):
+    """Throughput mode (submit batch i+1 before finishing batch i, two buffer sets) returns exactly what the
+    synchronous detect() returns for each batch, in order."""
+    model, cfg, sd = calibrated
+    model.backbone.compute_dtype = torch.bfloat16
+    eng = model.backbone.engine()
+    kw = dict(score_thr=0.02, nms_thr=0.5, mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD)
+    batches = [workload.synthetic_images(3, 96, 128, seed=40 + i, device="cuda") for i in range(5)]
+    want = []
+    for b in batches:
+        det, n = eng.detect(b, **kw)
+        want.append((det.clone(), n.clone()))
+    got = [(d.clone(), n.clone()) for d, n in eng.detect_pipelined(iter(batches), **kw)]
+    assert len(got) == len(want)
+    total = 0
+    for (d0, n0), (d1, n1) in zip(want, got):
+        assert torch.equal(n0, n1)
+        for i in range(d0.shape[0]):
+            k = int(n0[i])
+            total += k
+            assert torch.equal(d0[i, :k], d1[i, :k])
+    assert total > 0
+    model.backbone.compute_dtype = torch.float32

@@ -327,6 +327,14 @@ using namespace yolo;
 
 extern "C" int yolo_conv_cout_pad(int Cout) { return (Cout + 127) / 128 * 128; }
 
+extern "C" int yolo_conv_tile_shape(int M, int Cout, int* tile_channels, int* tile_pixels) {
+    YOLO_REQUIRE(M > 0 && Cout > 0 && tile_channels && tile_pixels, "conv_tile_shape: bad argument");
+    const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    *tile_channels = tc;
+    *tile_pixels = tc == 128 ? pick_tp(M, (Cout + tc - 1) / tc) : 128;
+    return YOLO_OK;
+}
+
 extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,
                                const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
                                int stride, float leaky_slope, int upsample2x, int dtype, int y_dtype, void* stream) {
@@ -404,7 +412,7 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
     p.upsample = upsample2x ? 1 : 0;
     p.y_f32 = y_dtype == YOLO_F32;
 
-    const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);  // keep in step with yolo_conv_tile_shape
     hipStream_t st = (hipStream_t)stream;
     if (dtype == YOLO_BF16) return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st);
     return dispatch_tc<float, false>(p, tc, st);

@@ -49,8 +49,19 @@ class Plan:
     nms_ws: Optional[torch.Tensor] = None
     keep: Optional[torch.Tensor] = None
     n_keep: Optional[torch.Tensor] = None
+    total_host: Optional[torch.Tensor] = None  # pinned int32[1]: candidate count read-back
     flops: int = 0  # conv multiply-add FLOPs (2 per MAC) of one forward at this batch
     meta: List[dict] = field(default_factory=list)  # per conv step: name, x, y, slope, residual, up
+
+
+@dataclass
+class InFlight:
+    """A batch whose convolutions and decode are queued on the GPU (Yolov3Engine.submit)."""
+    plan: Plan
+    cand: ops.Candidates
+    event: "torch.cuda.Event"
+    score_thr: float
+    geom: Tuple[int, int, int]  # N, stored image height, width
 
 
 class Yolov3Engine:
@@ -72,7 +83,8 @@ class Yolov3Engine:
         if self.device.type != "cuda":
             raise RuntimeError("Yolov3Engine needs the model on an MI355X (cuda device); there is no CPU path")
         self._packed: Dict[str, PackedConv] = {}
-        self._plans: Dict[Tuple[int, int, int], Plan] = {}
+        self._plans: Dict[Tuple[int, int, int, int], Plan] = {}
+        self._in_hw: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.repack()
 
     # ------------------------------------------------------------------ weights
@@ -89,8 +101,9 @@ class Yolov3Engine:
         self._plans.clear()
 
     # ------------------------------------------------------------------ plan
-    def plan(self, N: int, H: int, W: int) -> Plan:
-        key = (N, H, W)
+    def plan(self, N: int, H: int, W: int, slot: int = 0) -> Plan:
+        """Cached plan for a batch shape; plans with different ``slot`` own independent buffers."""
+        key = (N, H, W, slot)
         if key not in self._plans:
             self._plans[key] = self._build_plan(N, H, W)
         return self._plans[key]
@@ -189,13 +202,13 @@ class Yolov3Engine:
 
     # ------------------------------------------------------------------ execution
     def run_backbone(self, images: torch.Tensor, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0),
-                     padded_hw: Optional[Tuple[int, int]] = None) -> Plan:
+                     padded_hw: Optional[Tuple[int, int]] = None, plan: Optional[Plan] = None) -> Plan:
         """images: [N,3,Hs,Ws] float32 or uint8 on the GPU.  Pixel normalisation with (mean, std) and
         zero padding up to ``padded_hw`` happen inside the stem kernel."""
         N, _, Hs, Ws = images.shape
         if padded_hw is None:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
-        P = self.plan(N, padded_hw[0], padded_hw[1])
+        P = plan if plan is not None else self.plan(N, padded_hw[0], padded_hw[1])
         stem = self._packed["bottom_up.stem.conv"]
         if P.stem_fused_y is not None:
             d = self._packed["bottom_up.res1.0.downsample"]
@@ -222,18 +235,35 @@ class Yolov3Engine:
         return ops.decode(P.heads, self.strides, self.anchors_wh, self.num_classes, score_thr,
                           P.cand.scores.numel(), out=P.cand, workspace=P.decode_ws)
 
-    def detect(self, images: torch.Tensor, *, score_thr: float, nms_thr: float, mean, std,
-               padded_hw=None, max_det: int = 100, nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000,
-               in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
-        """Full inference for a batch.  Returns (det [N, max_det, 6], n_det [N]) on the GPU:
-        x0,y0,x1,y1 (output frame), score, class."""
-        P = self.run_backbone(images, mean, std, padded_hw)
+    def submit(self, images: torch.Tensor, *, score_thr: float, mean, std, padded_hw=None, slot: int = 0) -> "InFlight":
+        """First half of detect(): enqueue backbone + neck + heads + decode for a batch and start the
+        asynchronous read-back of the candidate count.  Nothing here waits for the GPU.  ``slot`` selects one of
+        several independent sets of activation buffers, so that batch i+1 can be submitted before batch i is
+        finished (finish() then overlaps with the GPU work already queued behind it)."""
+        N, _, Hs, Ws = images.shape
+        if padded_hw is None:
+            padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
+        P = self.plan(N, padded_hw[0], padded_hw[1], slot)
+        self.run_backbone(images, mean, std, padded_hw, plan=P)
         cand = self.decode(P, score_thr)
-        total = int(cand.img_offsets[P.N].item())  # the one host read-back per batch
+        if P.total_host is None:
+            P.total_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        P.total_host.copy_(cand.img_offsets[N:N + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return InFlight(P, cand, ev, score_thr, (N, Hs, Ws))
+
+    def finish(self, h: "InFlight", *, nms_thr: float, max_det: int = 100, nms_mode: int = ops.NMS_AUTO,
+               auto_limit: int = 20000, in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
+        """Second half of detect(): wait for the candidate count of a submitted batch (the one host read-back
+        per batch), then enqueue batched NMS + top-k gather.  Returns (det [N, max_det, 6], n_det [N])."""
+        P, cand = h.plan, h.cand
+        h.event.synchronize()
+        total = int(P.total_host[0])
         cap = cand.scores.numel()
         if total > cap:  # rare: grow and decode again (nothing was lost, only not written)
             P.cand = None
-            cand = self.decode(P, score_thr, cap=int(total * 1.25) + 1024)
+            cand = self.decode(P, h.score_thr, cap=int(total * 1.25) + 1024)
             total = int(cand.img_offsets[P.N].item())
         dev = self.device
         if P.keep is None or P.keep.shape[1] != max_det:
@@ -246,9 +276,35 @@ class Yolov3Engine:
         ops.batched_nms(cand.boxes, cand.scores, cand.classes, cand.img_offsets, total, nms_thr,
                         num_classes=self.num_classes, mode=nms_mode, auto_limit=auto_limit, top_k=max_det,
                         keep_stride=max_det, workspace=P.nms_ws, keep=P.keep, n_keep=P.n_keep)
-        N, Hs, Ws = images.shape[0], images.shape[2], images.shape[3]
-        if in_hw is None:
-            in_hw = torch.tensor([[Hs, Ws]] * N, dtype=torch.int32, device=dev)
+        N, Hs, Ws = h.geom
+        if in_hw is None:  # same stored size for the whole batch: cached, no host-to-device copy per call
+            if h.geom not in self._in_hw:
+                self._in_hw[h.geom] = torch.tensor([[Hs, Ws]] * N, dtype=torch.int32, device=dev)
+            in_hw = self._in_hw[h.geom]
         if out_hw is None:
             out_hw = in_hw
         return ops.gather_detections(cand, P.keep, P.n_keep, in_hw, out_hw)
+
+    def detect(self, images: torch.Tensor, *, score_thr: float, nms_thr: float, mean, std,
+               padded_hw=None, max_det: int = 100, nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000,
+               in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
+        """Full inference for a batch.  Returns (det [N, max_det, 6], n_det [N]) on the GPU:
+        x0,y0,x1,y1 (output frame), score, class."""
+        h = self.submit(images, score_thr=score_thr, mean=mean, std=std, padded_hw=padded_hw)
+        return self.finish(h, nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode, auto_limit=auto_limit,
+                           in_hw=in_hw, out_hw=out_hw)
+
+    def detect_pipelined(self, batches, *, score_thr: float, nms_thr: float, mean, std, max_det: int = 100,
+                         nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000, depth: int = 2):
+        """Throughput mode over an iterable of image batches: batch i+1's convolutions are queued before the
+        host waits for batch i's candidate count, so the GPU never idles on that read-back.  Yields
+        (det, n_det) per batch, in order; results of a batch are valid until ``depth`` more batches are submitted."""
+        pending: List[InFlight] = []
+        for i, images in enumerate(batches):
+            pending.append(self.submit(images, score_thr=score_thr, mean=mean, std=std, slot=i % depth))
+            if len(pending) == depth:
+                yield self.finish(pending.pop(0), nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode,
+                                  auto_limit=auto_limit)
+        while pending:
+            yield self.finish(pending.pop(0), nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode,
+                              auto_limit=auto_limit)

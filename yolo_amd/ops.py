@@ -136,6 +136,13 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, devi
     return wp.contiguous(), bp
 
 
+def conv_tile_shape(M: int, cout: int) -> Tuple[int, int]:
+    """(channels, pixels) of the workgroup tile yolo_conv2d_fwd picks for M output pixels, cout channels."""
+    tc, tp = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().yolo_conv_tile_shape(int(M), int(cout), ctypes.byref(tc), ctypes.byref(tp)), "yolo_conv_tile_shape")
+    return tc.value, tp.value
+
+
 def pack_stem(weight: torch.Tensor, bias: torch.Tensor, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """[Cout,3,3,3] -> [kh,kw,cin,Cout] f32."""
     return (weight.permute(2, 3, 1, 0).contiguous().float().to(device),
