@@ -47,17 +47,19 @@ def _barrier(world: int):
     torch.cuda.synchronize()
 
 
-def _dominant_kernel_roofline(eng, plan, convs, reps: int = 5):
+def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int = 3):
     """The dominant kernel is the 128-channel x 128-pixel bf16 implicit-GEMM instance
-    (conv_igemm_kernel<bf16,128,128,2,2,false>; yolo_conv_tile_shape says which launches use it).  Every such
-    launch of one step is timed with HIP events on the launch stream (``reps`` back-to-back launches per event
-    pair, so the figure is launch duration, not launch latency); achieved = its algorithmic FLOPs
-    (2 * pixels * Cout * Cin * k * k per launch) / its time.  The 128x96 instance of the same kernel, used where
-    it quantises better over the 512 resident workgroups, is reported next to it."""
+    (conv_igemm_kernel<bf16,128,128,2,2,false>; yolo_conv_tile_shape says which launches use it).  Its launches
+    are timed where they run: the whole plan is replayed in order with a HIP event pair (on the launch stream)
+    around each of them, so every launch sees the cache state it sees in a real step; the cost of an empty event
+    pair is measured the same way and subtracted.  achieved = algorithmic FLOPs (2 * pixels * Cout * Cin * k * k
+    per launch) / time.  The 128x96 instance of the same kernel, used where it quantises better over the 512
+    resident workgroups, is reported next to it."""
     from yolo_amd import ops
     stream = torch.cuda.current_stream()
-    acc = {128: [0.0, 0.0, 0], 96: [0.0, 0.0, 0]}  # flops, ms, launches
-    for meta, step in zip(plan.meta, plan.steps):
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    timed = []  # (step index, tile pixels, flops, bytes)
+    for i, (meta, step) in enumerate(zip(plan.meta, plan.steps)):
         c = convs[meta["name"]]
         if c.in_channels % 64 != 0:
             continue
@@ -66,25 +68,54 @@ def _dominant_kernel_roofline(eng, plan, convs, reps: int = 5):
         tc, tp = ops.conv_tile_shape(M, c.out_channels)
         if tc != 128:
             continue
-        fl = 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2
-        step()  # warm
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        for _ in range(reps):
-            step()
-        b.record(stream)
-        b.synchronize()
+        es = meta["x"].buf.element_size()
+        by = (plan.N * meta["x"].H * meta["x"].W * c.in_channels * es
+              + c.out_channels * c.in_channels * c.kernel_size ** 2 * es
+              + plan.N * meta["y"].H * meta["y"].W * c.out_channels * meta["y"].buf.element_size()
+              + (M * c.out_channels * es if meta["residual"] is not None else 0))
+        timed.append((i, tp, 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2, by))
+    which = {i: k for k, (i, _, _, _) in enumerate(timed)}
+    ms = [0.0] * len(timed)
+    empty = 0.0
+    for _ in range(passes):
+        pairs = [(ev(), ev()) for _ in timed]
+        e0, e1 = ev(), ev()
+        eng.run_backbone_prefix(images, mean, std, plan)  # fused stem + first-stage launches
+        for i, step in enumerate(plan.steps):
+            k = which.get(i)
+            if k is None:
+                step()
+            else:
+                pairs[k][0].record(stream)
+                step()
+                pairs[k][1].record(stream)
+        e0.record(stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        empty += e0.elapsed_time(e1) / passes
+        for k, (a, b) in enumerate(pairs):
+            ms[k] += a.elapsed_time(b) / passes
+    acc = {128: [0.0, 0.0, 0, 0.0], 96: [0.0, 0.0, 0, 0.0]}
+    for (i, tp, fl, by), t in zip(timed, ms):
         acc[tp][0] += fl
-        acc[tp][1] += a.elapsed_time(b) / reps
+        acc[tp][1] += max(t - empty, 1e-6)
         acc[tp][2] += 1
-    flops, ms, launches = acc[128]
-    achieved = flops / (ms * 1e-3) / 1e12
+        acc[tp][3] += by
+    flops, t128, launches, by128 = acc[128]
+    achieved = flops / (t128 * 1e-3) / 1e12
     out = dict(bound="mfma", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
                kernel="conv_igemm_kernel<bf16,128,128,2,2,false>", launches_per_step=launches,
-               avg_launch_us=round(ms * 1e3 / launches, 2), flop_per_launch=round(flops / launches / 1e9, 3))
+               avg_launch_us=round(t128 * 1e3 / launches, 2), flop_per_launch=round(flops / launches / 1e9, 3),
+               algorithmic_bytes_per_launch=round(by128 / launches), event_pair_overhead_us=round(empty * 1e3, 2))
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+        with open(pmc) as f:
+            rec = json.load(f)
+        out["traffic"] = rec.get("hbm_bytes_per_launch")
+        out["traffic_source"] = rec.get("source")
     if acc[96][2]:
-        f2, m2, l2 = acc[96]
+        f2, m2, l2, _ = acc[96]
         out["tile_128x96_instance"] = dict(achieved=round(f2 / (m2 * 1e-3) / 1e12, 1), launches_per_step=l2,
                                            avg_launch_us=round(m2 * 1e3 / l2, 2))
     return out
@@ -161,7 +192,7 @@ def main():
     out = None
     if rank == 0:
         convs = dict(model.backbone.darknet_modules())
-        roof = _dominant_kernel_roofline(eng, plan, convs)
+        roof = _dominant_kernel_roofline(eng, plan, convs, imgs, mean, std)
         n_cand = int(plan.cand.img_offsets[BATCH].item())
         out = {
             "metric": "images/sec YOLOv3-416 inference incl. decode+NMS",

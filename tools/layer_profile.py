@@ -46,6 +46,11 @@ def main():
         fl = 2 * N * size * size * 32 * 27
         by = N * size * size * (3 + 32 * 2)
         rows.append(("stem", 3, 32, 3, 1, size, t, fl, by))
+    for i, step in enumerate(P.pre_steps):  # fused residual blocks of the first stage (64 channels)
+        h = size // 2
+        fl = 2 * N * h * h * (32 * 64 + 64 * 32 * 9)
+        by = N * h * h * 64 * 2 * 2
+        rows.append((f"bottom_up.res1.{i} (fused block)", 64, 64, 3, 1, h, timeit(step), fl, by))
     for meta, step in zip(P.meta, P.steps):
         c = convs[meta["name"]]
         y = meta["y"]

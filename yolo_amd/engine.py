@@ -209,6 +209,14 @@ class Yolov3Engine:
         if padded_hw is None:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         P = plan if plan is not None else self.plan(N, padded_hw[0], padded_hw[1])
+        self.run_backbone_prefix(images, mean, std, P)
+        for step in P.steps:
+            step()
+        return P
+
+    def run_backbone_prefix(self, images: torch.Tensor, mean, std, P: Plan) -> None:
+        """The launches that precede ``P.steps``: stem (fused with the first down-sampling conv in bf16) and the
+        fused residual blocks of the first stage."""
         stem = self._packed["bottom_up.stem.conv"]
         if P.stem_fused_y is not None:
             d = self._packed["bottom_up.res1.0.downsample"]
@@ -218,9 +226,6 @@ class Yolov3Engine:
             ops.stem_fwd(images.contiguous(), stem.w, stem.b, P.stem_out, mean=mean, std=std)
         for step in P.pre_steps:
             step()
-        for step in P.steps:
-            step()
-        return P
 
     def decode(self, P: Plan, score_thr: float, cap: Optional[int] = None) -> ops.Candidates:
         if cap is None:
