@@ -205,6 +205,56 @@ int yolo_gather_detections(const float* boxes, const float* scores, const int* c
                            int N, const int* in_hw, const int* out_hw,
                            float* det, int* n_det, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training path (reference: tools/train_net.py -> detectron2 DefaultTrainer: losses = model(batch);
+ * losses.backward(); optimizer.step()).  Modules in training mode run convolution, batch-statistics
+ * BatchNorm and LeakyReLU as separate steps; yolo_conv2d_fwd (leaky_slope 1, zero bias) is the convolution,
+ * and also the data gradient: dX of a stride-1 conv is yolo_conv2d_fwd of dZ with the weights transposed
+ * (Cin <-> Cout) and rotated by 180 degrees; for stride 2, of yolo_dilate2x_nhwc(dZ).
+ * ------------------------------------------------------------------------------------------------ */
+
+/*
+ * Batch statistics of a conv output z (the BatchNorm2d that detectron2's Conv2d applies after F.conv2d in
+ * training mode; modules built by get_norm("BN") at darknet.py:45-53,74-106, fpn.py:23-30,44-61,78-90).
+ *   stats  [5][C] f32 out: mean, biased variance, 1/sqrt(var+eps), scale = gamma/sqrt(var+eps),
+ *          shift = beta - mean*scale
+ *   running_mean/var  NULL, or updated in place as torch does: (1-momentum)*old + momentum*new, with the
+ *          UNBIASED batch variance
+ *   C = 8 * power of two, <= 2048;  workspace: yolo_bn_workspace_bytes(N, H, W, C)
+ */
+int yolo_bn_train_stats(const yolo_view* z, int N, int C, int dtype, const float* gamma, const float* beta,
+                        float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                        void* workspace, size_t ws_bytes, void* stream);
+size_t yolo_bn_workspace_bytes(int N, int H, int W, int C);
+
+/* y = leaky(z*scale + shift) [+ residual]: BatchNorm2d (training) + F.leaky_relu (darknet.py:59,116,120,123;
+ * fpn.py:35,69,98) + `out += residual` (darknet.py:125).  stats from yolo_bn_train_stats. */
+int yolo_bn_act_fwd(const yolo_view* z, const float* stats, const yolo_view* residual, const yolo_view* y,
+                    int N, int C, float leaky_slope, int dtype, void* stream);
+
+/* Backward of yolo_bn_act_fwd (without the residual, whose gradient is dy itself): given dy and the saved z
+ * and stats, writes dgamma [C], dbeta [C] (f32) and dz = scale*(g - mean(g) - zhat*mean(g*zhat)),
+ * g = dy*leaky'(z*scale+shift), zhat = (z-mean)/sqrt(var+eps) -- what autograd derives for
+ * F.batch_norm(training=True) + F.leaky_relu. */
+int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const float* stats, const yolo_view* dz,
+                    int N, int C, float leaky_slope, int dtype, float* dgamma, float* dbeta,
+                    void* workspace, size_t ws_bytes, void* stream);
+
+/*
+ * Weight gradient of F.conv2d (bf16 operands, f32 result):
+ *   dw[co][kh][kw][ci] (+)= sum_{n,ho,wo} dz[n][ho][wo][co] * x[n][ho*stride+kh-pad][wo*stride+kw-pad][ci]
+ *   x   input view of the forward conv (halo >= pad);  dz  gradient view of its output (zero halo >= 1 unless
+ *   N*Ho*Wo % 32 == 0);  accumulate != 0 adds to dw;  workspace: yolo_conv2d_wgrad_workspace_bytes(N*Ho*Wo, ...)
+ */
+int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N, int Cin, int Cout, int k, int stride,
+                      float* dw, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k);
+
+/* y[2i][2j] = x[i][j], zeros elsewhere in each 2x2 cell (input of a stride-2 conv's data gradient). */
+int yolo_dilate2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
+/* y[i][j] = sum of the 2x2 cell of x: backward of nn.Upsample(2, "nearest") (fpn.py:31,36). */
+int yolo_sum2x2_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,156 @@
+"""GPU parity of the training-path kernels (batch-statistics BatchNorm + LeakyReLU forward/backward, conv weight
+gradient, conv data gradient through yolo_conv2d_fwd, 2x dilation / 2x2 sum) against torch CPU autograd on the
+same bf16-rounded operands -- the operations autograd runs for detectron2's Conv2d (F.conv2d + BatchNorm2d) and
+F.leaky_relu in the reference's training step (yolo/modeling/backbone/darknet.py:113-126, fpn.py:33-37,66-71,96-100).
+
+Tolerances: fp32 1e-3, bf16 5e-2 relative to the tensor's max (the task's conv/head bars), plus a mean-error bound.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    return float((got.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 13, 11), (2, 32, 40, 24), (2, 1024, 5, 3), (4, 256, 8, 8)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_bn_act_train_fwd_bwd(cuda, shape, dtype):
+    from yolo_amd import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    z = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).to(dtype).float()
+    res = torch.randn(N, C, H, W, generator=g).to(dtype).float()
+    gamma = 0.5 + torch.rand(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    dy = torch.randn(N, C, H, W, generator=g).to(dtype).float()
+
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.leaky_relu(F.batch_norm(zr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5), 0.1) + res
+    y_ref.backward(dy)
+
+    zv = ops.view_from_nchw(z.to(cuda), 1, dtype)
+    rvw = ops.view_from_nchw(res.to(cuda), 0, dtype)
+    yv = ops.alloc_view(N, H, W, C, 1, dtype, cuda)
+    stats = torch.empty(5, C, device=cuda)
+    ws = torch.empty(ops.bn_workspace_bytes(N, H, W, C), dtype=torch.uint8, device=cuda)
+    rm_d, rv_d = rm.to(cuda), rv.to(cuda)
+    ops.bn_train_stats(zv, gamma.to(cuda), beta.to(cuda), stats, ws, running_mean=rm_d, running_var=rv_d)
+    ops.bn_act_fwd(zv, stats, yv, slope=0.1, residual=rvw)
+    torch.cuda.synchronize()
+    tol = 1e-3 if dtype == torch.float32 else 5e-2
+    assert _rel(stats[0].cpu(), z.mean(dim=(0, 2, 3))) < 1e-4
+    assert _rel(stats[1].cpu(), z.var(dim=(0, 2, 3), unbiased=False)) < 1e-4
+    assert _rel(rm_d.cpu(), rm_ref) < 1e-4 and _rel(rv_d.cpu(), rv_ref) < 1e-4
+    assert _rel(yv.nchw().float().cpu(), y_ref.detach()) < tol
+    assert float(yv.buf[:, 0].abs().max()) == 0.0
+
+    dyv = ops.view_from_nchw(dy.to(cuda), 0, dtype)
+    dzv = ops.alloc_view(N, H, W, C, 1, dtype, cuda)
+    dgam, dbet = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    ops.bn_act_bwd(dyv, zv, stats, dzv, dgam, dbet, ws, slope=0.1)
+    torch.cuda.synchronize()
+    assert _rel(dgam.cpu(), gr.grad) < 1e-3
+    assert _rel(dbet.cpu(), br.grad) < 1e-3
+    assert _rel(dzv.nchw().float().cpu(), zr.grad) < tol
+    assert float(dzv.buf[:, :, 0].abs().max()) == 0.0
+
+
+# (Cin, Cout, k, stride, H, W)
+WGRAD_SHAPES = [(64, 128, 3, 1, 9, 7), (128, 64, 1, 1, 9, 7), (64, 128, 3, 2, 14, 10), (256, 512, 3, 1, 5, 4),
+                (512, 255, 1, 1, 4, 4), (1024, 512, 1, 1, 3, 3), (32, 64, 3, 1, 13, 11), (384, 128, 1, 1, 6, 6),
+                (128, 256, 3, 2, 10, 10), (256, 128, 1, 1, 26, 26)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv_wgrad(cuda, shape):
+    from yolo_amd import ops
+    cin, cout, k, stride, H, W = shape
+    g = torch.Generator().manual_seed(cin + 3 * cout + H)
+    N = 3
+    x = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    w = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2)
+    dz = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dz)
+    Ho, Wo = y.shape[2], y.shape[3]
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    cpad = (cout + 7) // 8 * 8
+    dzv = ops.alloc_view(N, Ho, Wo, cpad, 1, torch.bfloat16, cuda)
+    dzv.interior()[..., :cout].copy_(dz.to(cuda).permute(0, 2, 3, 1))
+    if cpad != cout:
+        dzv.interior()[..., cout:] = 7.0  # pad channels must not leak into the result
+    dw = torch.full((cout, k, k, cin), 3.0, device=cuda)
+    ws = torch.empty(ops.wgrad_workspace_bytes(N * Ho * Wo, cin, cout, k), dtype=torch.uint8, device=cuda)
+    ops.conv2d_wgrad(xv, dzv, dw, ws, cin=cin, cout=cout, k=k, stride=stride)
+    torch.cuda.synchronize()
+    got = dw.permute(0, 3, 1, 2).cpu()
+    assert _rel(got, w.grad) < 1e-3  # bf16 operands are exact inputs here; fp32 accumulation
+    ops.conv2d_wgrad(xv, dzv, dw, ws, cin=cin, cout=cout, k=k, stride=stride, accumulate=True)
+    torch.cuda.synchronize()
+    assert _rel(dw.permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 3, 1, 9, 7), (128, 64, 1, 1, 9, 7), (64, 128, 3, 2, 14, 10),
+                                   (512, 255, 1, 1, 4, 4), (128, 256, 3, 2, 10, 12)], ids=lambda s: "x".join(map(str, s)))
+def test_conv_dgrad_via_fwd_kernel(cuda, shape):
+    """dX = conv(dZ [dilated for stride 2], W transposed + rotated), with an accumulated second term."""
+    from yolo_amd import ops
+    cin, cout, k, stride, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    N = 2
+    x = torch.randn(N, cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).bfloat16().float()
+    y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2)
+    dz = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dz)
+    other = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    ref = x.grad + other
+    Ho, Wo = y.shape[2], y.shape[3]
+    cpad = (cout + 63) // 64 * 64  # the data-gradient conv reads Cout as ITS input channels
+    dzv = ops.alloc_view(N, Ho, Wo, cpad, 1, torch.bfloat16, cuda)
+    dzv.interior()[..., :cout].copy_(dz.to(cuda).permute(0, 2, 3, 1))
+    wpad = torch.zeros(cpad, cin, k, k)
+    wpad[:cout] = w
+    wp, bp = ops.pack_conv_dgrad(wpad, torch.bfloat16, cuda)
+    if stride == 2:
+        big = ops.alloc_view(N, 2 * Ho, 2 * Wo, cpad, 1, torch.bfloat16, cuda)
+        ops.dilate2x(dzv, big)
+        src = big
+        assert (2 * Ho, 2 * Wo) == (H, W)
+    else:
+        src = dzv
+    dxv = ops.view_from_nchw(other.to(cuda), 1, torch.bfloat16)
+    ops.conv2d_fwd(src, wp, bp, dxv, cin=cpad, cout=cin, k=k, stride=1, slope=1.0, residual=dxv)
+    torch.cuda.synchronize()
+    assert _rel(dxv.nchw().float().cpu(), ref) < 5e-2
+    assert float((dxv.nchw().float().cpu() - ref).abs().mean() / ref.abs().mean()) < 4e-3
+
+
+def test_dilate_and_sum2x2(cuda):
+    from yolo_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 64, 5, 7, generator=g).bfloat16().float()
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    big = ops.alloc_view(2, 10, 14, 128, 1, torch.bfloat16, cuda)
+    big.buf.fill_(5.0)
+    ops.dilate2x(xv, big.slice(64, 64))
+    torch.cuda.synchronize()
+    got = big.nchw().float().cpu()
+    ref = torch.zeros(2, 64, 10, 14)
+    ref[:, :, ::2, ::2] = x
+    assert torch.equal(got[:, 64:], ref) and bool((got[:, :64] == 5.0).all())
+    up = torch.randn(2, 64, 10, 14, generator=g).bfloat16().float()
+    uv = ops.view_from_nchw(up.to(cuda), 0, torch.bfloat16)
+    sv = ops.alloc_view(2, 5, 7, 64, 1, torch.bfloat16, cuda)
+    ops.sum2x2(uv, sv)
+    torch.cuda.synchronize()
+    ref = F.avg_pool2d(up, 2) * 4
+    assert _rel(sv.nchw().float().cpu(), ref) < 1e-2

@@ -39,6 +39,17 @@ SIGNATURES = {
     "yolo_stem_down_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p, c_void_p, c_void_p,
                                    c_void_p, _VP, c_int, c_int, c_float, c_void_p]),
     "yolo_resblock_c64_fwd": (c_int, [_VP, c_void_p, c_void_p, c_void_p, c_void_p, _VP, c_int, c_float, c_void_p]),
+    "yolo_bn_train_stats": (c_int, [_VP, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "yolo_bn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "yolo_bn_act_fwd": (c_int, [_VP, c_void_p, _VP, _VP, c_int, c_int, c_float, c_int, c_void_p]),
+    "yolo_bn_act_bwd": (c_int, [_VP, _VP, c_void_p, _VP, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
+    "yolo_conv2d_wgrad": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
+    "yolo_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "yolo_dilate2x_nhwc": (c_int, [_VP, _VP, c_int, c_int, c_int, c_void_p]),
+    "yolo_sum2x2_nhwc": (c_int, [_VP, _VP, c_int, c_int, c_int, c_void_p]),
     "yolo_upsample2x_nhwc": (c_int, [_VP, _VP, c_int, c_int, c_int, c_void_p]),
     "yolo_decode": (c_int, [_VP, c_int, _IP, _FP, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,540 @@
+// Training-mode BatchNorm + LeakyReLU (forward and backward) and the small data-movement kernels of the
+// backward pass, for gfx950.  NHWC views as everywhere in this library; all of these are HBM-bound streaming
+// kernels: 16 bytes per lane per access, fp32 arithmetic, fp32/fp64 reductions.
+//
+// Replaces, for modules in training mode, the BatchNorm2d that detectron2's Conv2d.forward applies after
+// F.conv2d (built by get_norm("BN"); yolo/modeling/backbone/darknet.py:45-53,74-106, fpn.py:23-30,44-61,78-90),
+// the F.leaky_relu that follows it (darknet.py:59,116,120,123; fpn.py:35,69,98), the `out += residual` of
+// darknet.py:125, and their autograd backward; plus the backward of nn.Upsample(2, "nearest") (fpn.py:31,36)
+// and the zero insertion that turns the data gradient of a stride-2 convolution into a stride-1 one.
+#include "common.h"
+
+namespace yolo {
+
+struct RedParams {
+    const char* a;  // z (stats) or dy (backward)
+    const char* z;  // backward only
+    long long a_img_stride, a_origin, z_img_stride, z_origin;  // bytes
+    int a_row_stride, a_pix_stride, z_row_stride, z_pix_stride;  // bytes
+    int H, W, C, G;          // G = C/8 channel groups
+    long long M;             // N*H*W pixels
+    int chunk;               // pixels per block
+    const float* scale;      // backward: gamma * invstd  [C]
+    const float* shift;      // backward: beta - mean * scale
+    const float* mean;       // backward
+    const float* invstd;     // backward
+    float slope;
+    float* partial;          // [blocks][2][C]
+};
+
+template <typename T>
+__device__ __forceinline__ void load8(const char* p, float v[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const u32x4 r = *(const u32x4*)p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __uint_as_float(r[e] << 16);
+            v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u);
+        }
+    } else {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = a[e];
+            v[4 + e] = b[e];
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(char* p, const float v[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const u32x4 r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                         pack_bf16x2(v[6], v[7])};
+        *(u32x4*)p = r;
+    } else {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 16) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// Per-channel partial sums over a chunk of pixels.  MODE 0: (sum z, sum z^2).  MODE 1: with
+// g = dy * leaky'(z*scale + shift): (sum g, sum g * zhat), zhat = (z - mean) * invstd.
+// Thread = (pixel lane, 8-channel group); the pixel lanes of a block are folded through LDS.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
+    __shared__ float red[2][256][8];
+    const int tid = threadIdx.x;
+    const int g = tid % p.G, pl = tid / p.G, PL = 256 / p.G;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    float sc[8], sh[8], mu[8], is[8];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = p.scale[g * 8 + e];
+            sh[e] = p.shift[g * 8 + e];
+            mu[e] = p.mean[g * 8 + e];
+            is[e] = p.invstd[g * 8 + e];
+        }
+    }
+    const long long m0 = (long long)blockIdx.x * p.chunk;
+    const long long m1 = m0 + p.chunk < p.M ? m0 + p.chunk : p.M;
+    const int HW = p.H * p.W;
+    for (long long m = m0 + pl; m < m1; m += PL) {
+        const int n = (int)(m / HW);
+        const int r = (int)(m - (long long)n * HW);
+        const int h = r / p.W, w = r - h * p.W;
+        float a[8];
+        load8<T>(p.a + p.a_origin + n * p.a_img_stride + (long long)h * p.a_row_stride + w * p.a_pix_stride +
+                     g * 8 * (int)sizeof(T),
+                 a);
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s0[e] += a[e];
+                s1[e] += a[e] * a[e];
+            }
+        } else {
+            float z[8];
+            load8<T>(p.z + p.z_origin + n * p.z_img_stride + (long long)h * p.z_row_stride + w * p.z_pix_stride +
+                         g * 8 * (int)sizeof(T),
+                     z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pre = z[e] * sc[e] + sh[e];
+                const float gr = pre >= 0.f ? a[e] : a[e] * p.slope;
+                s0[e] += gr;
+                s1[e] += gr * ((z[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[0][tid][e] = s0[e];
+        red[1][tid][e] = s1[e];
+    }
+    __syncthreads();
+    // thread t < 2*C: which = t / C, channel c = t % C: fold the PL pixel lanes
+    for (int t = tid; t < 2 * p.C; t += 256) {
+        const int which = t / p.C, c = t - which * p.C;
+        const int gg = c >> 3, e = c & 7;
+        float acc = 0.f;
+        for (int l = 0; l < PL; ++l) acc += red[which][l * p.G + gg][e];
+        p.partial[((long long)blockIdx.x * 2 + which) * p.C + c] = acc;
+    }
+}
+
+struct FinParams {
+    const float* partial;
+    int blocks, C;
+    double count;  // N*H*W
+    // stats mode
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* mean;
+    float* var;
+    float* invstd;
+    float* scale;
+    float* shift;
+    float* running_mean;  // may be null
+    float* running_var;
+    // backward mode
+    float* dgamma;
+    float* dbeta;
+};
+
+// One thread per channel; partials are folded in double precision.
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const FinParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < p.blocks; ++i) {
+        a += (double)p.partial[((long long)i * 2 + 0) * p.C + c];
+        b += (double)p.partial[((long long)i * 2 + 1) * p.C + c];
+    }
+    if constexpr (MODE == 0) {
+        const double mean = a / p.count;
+        double var = b / p.count - mean * mean;  // biased, what the normalisation uses
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float sc = p.gamma[c] * invstd;
+        p.mean[c] = (float)mean;
+        p.var[c] = (float)var;
+        p.invstd[c] = invstd;
+        p.scale[c] = sc;
+        p.shift[c] = p.beta[c] - (float)mean * sc;
+        if (p.running_mean) {  // torch BatchNorm2d: momentum update with the UNBIASED variance
+            const double unb = p.count > 1.0 ? var * (p.count / (p.count - 1.0)) : var;
+            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+        }
+    } else {
+        p.dbeta[c] = (float)a;
+        p.dgamma[c] = (float)b;
+    }
+}
+
+struct ApplyParams {
+    const char* z;
+    const char* r;  // forward: residual (may be null); backward: dy
+    char* y;        // forward: y; backward: dz
+    long long z_img_stride, z_origin, r_img_stride, r_origin, y_img_stride, y_origin;  // bytes
+    int z_row_stride, z_pix_stride, r_row_stride, r_pix_stride, y_row_stride, y_pix_stride;
+    int H, W, C, G;
+    long long total;  // N*H*W*G
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    const float* dgamma;
+    const float* dbeta;
+    float slope, inv_count;
+};
+
+// MODE 0: y = leaky(z*scale + shift) (+ r).  MODE 1: dz = scale * (g - dbeta/M - zhat * dgamma/M),
+// g = dy * leaky'(z*scale + shift).
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const ApplyParams p) {
+    const int HW = p.H * p.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % p.G);
+        const long long m = i / p.G;
+        const int n = (int)(m / HW);
+        const int rr = (int)(m - (long long)n * HW);
+        const int h = rr / p.W, w = rr - h * p.W;
+        const int cb = g * 8 * (int)sizeof(T);
+        float z[8], o[8];
+        load8<T>(p.z + p.z_origin + n * p.z_img_stride + (long long)h * p.z_row_stride + w * p.z_pix_stride + cb, z);
+        const f32x4 sc0 = *(const f32x4*)(p.scale + g * 8), sc1 = *(const f32x4*)(p.scale + g * 8 + 4);
+        const f32x4 sh0 = *(const f32x4*)(p.shift + g * 8), sh1 = *(const f32x4*)(p.shift + g * 8 + 4);
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pre = z[e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                o[e] = pre >= 0.f ? pre : pre * p.slope;
+            }
+            if (p.r) {
+                float r[8];
+                load8<T>(p.r + p.r_origin + n * p.r_img_stride + (long long)h * p.r_row_stride + w * p.r_pix_stride + cb, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += r[e];
+            }
+        } else {
+            float dy[8];
+            load8<T>(p.r + p.r_origin + n * p.r_img_stride + (long long)h * p.r_row_stride + w * p.r_pix_stride + cb, dy);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = g * 8 + e;
+                const float sc = e < 4 ? sc0[e & 3] : sc1[e & 3];
+                const float pre = z[e] * sc + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                const float gr = pre >= 0.f ? dy[e] : dy[e] * p.slope;
+                const float zh = (z[e] - p.mean[c]) * p.invstd[c];
+                o[e] = sc * (gr - p.dbeta[c] * p.inv_count - zh * p.dgamma[c] * p.inv_count);
+            }
+        }
+        store8<T>(p.y + p.y_origin + n * p.y_img_stride + (long long)h * p.y_row_stride + w * p.y_pix_stride + cb, o);
+    }
+}
+
+struct MoveParams {
+    const char* x;
+    char* y;
+    long long x_img_stride, x_origin, y_img_stride, y_origin;  // bytes
+    int x_row_stride, x_pix_stride, y_row_stride, y_pix_stride;
+    int H, W, G;  // size of the SMALLER side (x for dilate, y for the 2x2 sum)
+    long long total;
+};
+
+// y[2i][2j] = x[i][j], the other three positions of each 2x2 cell = 0
+template <typename T>
+__global__ void __launch_bounds__(256) dilate2x_kernel(const MoveParams p) {
+    const int HW = p.H * p.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % p.G);
+        const long long m = i / p.G;
+        const int n = (int)(m / HW);
+        const int rr = (int)(m - (long long)n * HW);
+        const int h = rr / p.W, w = rr - h * p.W;
+        const int cb = g * 8 * (int)sizeof(T);
+        float v[8];
+        const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        load8<T>(p.x + p.x_origin + n * p.x_img_stride + (long long)h * p.x_row_stride + w * p.x_pix_stride + cb, v);
+        char* o = p.y + p.y_origin + n * p.y_img_stride + (long long)(2 * h) * p.y_row_stride + (2 * w) * p.y_pix_stride + cb;
+        store8<T>(o, v);
+        store8<T>(o + p.y_pix_stride, zero);
+        store8<T>(o + p.y_row_stride, zero);
+        store8<T>(o + p.y_row_stride + p.y_pix_stride, zero);
+    }
+}
+
+// y[i][j] = x[2i][2j] + x[2i][2j+1] + x[2i+1][2j] + x[2i+1][2j+1]   (backward of nearest 2x upsampling)
+template <typename T>
+__global__ void __launch_bounds__(256) sum2x2_kernel(const MoveParams p) {
+    const int HW = p.H * p.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % p.G);
+        const long long m = i / p.G;
+        const int n = (int)(m / HW);
+        const int rr = (int)(m - (long long)n * HW);
+        const int h = rr / p.W, w = rr - h * p.W;
+        const int cb = g * 8 * (int)sizeof(T);
+        const char* s = p.x + p.x_origin + n * p.x_img_stride + (long long)(2 * h) * p.x_row_stride + (2 * w) * p.x_pix_stride + cb;
+        float a[8], b[8], c[8], d[8], o[8];
+        load8<T>(s, a);
+        load8<T>(s + p.x_pix_stride, b);
+        load8<T>(s + p.x_row_stride, c);
+        load8<T>(s + p.x_row_stride + p.x_pix_stride, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (a[e] + b[e]) + (c[e] + d[e]);
+        store8<T>(p.y + p.y_origin + n * p.y_img_stride + (long long)h * p.y_row_stride + w * p.y_pix_stride + cb, o);
+    }
+}
+
+static int check_slice(const yolo_view* v, int C, const char* what) {
+    YOLO_REQUIRE(v && v->ptr && v->H > 0 && v->W > 0, "%s: bad view", what);
+    YOLO_REQUIRE(C > 0 && C % 8 == 0 && v->ch_offset % 8 == 0 && v->ch_total % 8 == 0 && v->ch_offset + C <= v->ch_total,
+                 "%s: needs an 8-aligned slice of %d channels", what, C);
+    return YOLO_OK;
+}
+
+static int red_blocks(long long M, int* chunk) {
+    long long c = (M + 2047) / 2048;
+    if (c < 64) c = 64;
+    *chunk = (int)c;
+    return (int)((M + c - 1) / c);
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" size_t yolo_bn_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    int chunk;
+    const int blocks = red_blocks((long long)N * H * W, &chunk);
+    return (size_t)blocks * 2 * C * sizeof(float);
+}
+
+extern "C" int yolo_bn_train_stats(const yolo_view* z, int N, int C, int dtype, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                                   void* workspace, size_t ws_bytes, void* stream) {
+    YOLO_REQUIRE(gamma && beta && stats && workspace, "bn_train_stats: null argument");
+    if (int e = check_slice(z, C, "bn_train_stats")) return e;
+    YOLO_REQUIRE(C <= 2048 && (C / 8 & (C / 8 - 1)) == 0 && C / 8 <= 256, "bn_train_stats: C %d (8 * power of two, <= 2048)", C);
+    YOLO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come in pairs");
+    YOLO_REQUIRE(ws_bytes >= yolo_bn_workspace_bytes(N, z->H, z->W, C), "bn_train_stats: workspace too small");
+    const int es = (int)elem_size(dtype);
+    const ViewGeom g = geom_of(*z);
+    RedParams p{};
+    p.a = (const char*)z->ptr;
+    p.a_img_stride = g.img_stride * es;
+    p.a_row_stride = g.row_stride * es;
+    p.a_pix_stride = g.pix_stride * es;
+    p.a_origin = (long long)g.origin * es;
+    p.H = z->H;
+    p.W = z->W;
+    p.C = C;
+    p.G = C / 8;
+    p.M = (long long)N * z->H * z->W;
+    const int blocks = red_blocks(p.M, &p.chunk);
+    p.partial = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((bn_reduce_kernel<unsigned short, 0>), dim3(blocks), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(blocks), dim3(256), 0, st, p);
+    FinParams f{};
+    f.partial = p.partial;
+    f.blocks = blocks;
+    f.C = C;
+    f.count = (double)p.M;
+    f.gamma = gamma;
+    f.beta = beta;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean = stats;
+    f.var = stats + C;
+    f.invstd = stats + 2 * C;
+    f.scale = stats + 3 * C;
+    f.shift = stats + 4 * C;
+    f.running_mean = running_mean;
+    f.running_var = running_var;
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((C + 255) / 256), dim3(256), 0, st, f);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+static void fill_apply(ApplyParams& p, const yolo_view* z, const yolo_view* r, const yolo_view* y, int N, int C, int es) {
+    const ViewGeom gz = geom_of(*z), gy = geom_of(*y);
+    p.z = (const char*)z->ptr;
+    p.z_img_stride = gz.img_stride * es;
+    p.z_row_stride = gz.row_stride * es;
+    p.z_pix_stride = gz.pix_stride * es;
+    p.z_origin = (long long)gz.origin * es;
+    p.y = (char*)y->ptr;
+    p.y_img_stride = gy.img_stride * es;
+    p.y_row_stride = gy.row_stride * es;
+    p.y_pix_stride = gy.pix_stride * es;
+    p.y_origin = (long long)gy.origin * es;
+    if (r) {
+        const ViewGeom gr = geom_of(*r);
+        p.r = (const char*)r->ptr;
+        p.r_img_stride = gr.img_stride * es;
+        p.r_row_stride = gr.row_stride * es;
+        p.r_pix_stride = gr.pix_stride * es;
+        p.r_origin = (long long)gr.origin * es;
+    }
+    p.H = z->H;
+    p.W = z->W;
+    p.C = C;
+    p.G = C / 8;
+    p.total = (long long)N * z->H * z->W * p.G;
+}
+
+static unsigned apply_grid(long long total) {
+    long long b = (total + 255) / 256;
+    return (unsigned)(b < 8192 ? b : 8192);
+}
+
+extern "C" int yolo_bn_act_fwd(const yolo_view* z, const float* stats, const yolo_view* residual, const yolo_view* y,
+                               int N, int C, float leaky_slope, int dtype, void* stream) {
+    YOLO_REQUIRE(stats, "bn_act_fwd: null argument");
+    if (int e = check_slice(z, C, "bn_act_fwd")) return e;
+    if (int e = check_slice(y, C, "bn_act_fwd")) return e;
+    YOLO_REQUIRE(y->H == z->H && y->W == z->W, "bn_act_fwd: z and y differ in size");
+    if (residual) {
+        if (int e = check_slice(residual, C, "bn_act_fwd")) return e;
+        YOLO_REQUIRE(residual->H == z->H && residual->W == z->W, "bn_act_fwd: residual size");
+    }
+    ApplyParams p{};
+    fill_apply(p, z, residual, y, N, C, (int)elem_size(dtype));
+    p.scale = stats + 3 * C;
+    p.shift = stats + 4 * C;
+    p.slope = leaky_slope;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<unsigned short, 0>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<float, 0>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const float* stats, const yolo_view* dz, int N,
+                               int C, float leaky_slope, int dtype, float* dgamma, float* dbeta, void* workspace,
+                               size_t ws_bytes, void* stream) {
+    YOLO_REQUIRE(stats && dgamma && dbeta && workspace, "bn_act_bwd: null argument");
+    if (int e = check_slice(dy, C, "bn_act_bwd")) return e;
+    if (int e = check_slice(z, C, "bn_act_bwd")) return e;
+    if (int e = check_slice(dz, C, "bn_act_bwd")) return e;
+    YOLO_REQUIRE(dy->H == z->H && dy->W == z->W && dz->H == z->H && dz->W == z->W, "bn_act_bwd: sizes differ");
+    YOLO_REQUIRE(C <= 2048 && (C / 8 & (C / 8 - 1)) == 0 && C / 8 <= 256, "bn_act_bwd: C %d (8 * power of two, <= 2048)", C);
+    YOLO_REQUIRE(ws_bytes >= yolo_bn_workspace_bytes(N, z->H, z->W, C), "bn_act_bwd: workspace too small");
+    const int es = (int)elem_size(dtype);
+    const ViewGeom ga = geom_of(*dy), gz = geom_of(*z);
+    RedParams r{};
+    r.a = (const char*)dy->ptr;
+    r.a_img_stride = ga.img_stride * es;
+    r.a_row_stride = ga.row_stride * es;
+    r.a_pix_stride = ga.pix_stride * es;
+    r.a_origin = (long long)ga.origin * es;
+    r.z = (const char*)z->ptr;
+    r.z_img_stride = gz.img_stride * es;
+    r.z_row_stride = gz.row_stride * es;
+    r.z_pix_stride = gz.pix_stride * es;
+    r.z_origin = (long long)gz.origin * es;
+    r.H = z->H;
+    r.W = z->W;
+    r.C = C;
+    r.G = C / 8;
+    r.M = (long long)N * z->H * z->W;
+    const int blocks = red_blocks(r.M, &r.chunk);
+    r.mean = stats;
+    r.invstd = stats + 2 * C;
+    r.scale = stats + 3 * C;
+    r.shift = stats + 4 * C;
+    r.slope = leaky_slope;
+    r.partial = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((bn_reduce_kernel<unsigned short, 1>), dim3(blocks), dim3(256), 0, st, r);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(blocks), dim3(256), 0, st, r);
+    FinParams f{};
+    f.partial = r.partial;
+    f.blocks = blocks;
+    f.C = C;
+    f.count = (double)r.M;
+    f.dgamma = dgamma;
+    f.dbeta = dbeta;
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((C + 255) / 256), dim3(256), 0, st, f);
+    ApplyParams p{};
+    fill_apply(p, z, dy, dz, N, C, es);
+    p.mean = stats;
+    p.invstd = stats + 2 * C;
+    p.scale = stats + 3 * C;
+    p.shift = stats + 4 * C;
+    p.dgamma = dgamma;
+    p.dbeta = dbeta;
+    p.slope = leaky_slope;
+    p.inv_count = (float)(1.0 / (double)r.M);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<unsigned short, 1>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<float, 1>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+static int move_common(MoveParams& p, const yolo_view* x, const yolo_view* y, int N, int C, int es, bool x_small) {
+    const ViewGeom gx = geom_of(*x), gy = geom_of(*y);
+    p.x = (const char*)x->ptr;
+    p.x_img_stride = gx.img_stride * es;
+    p.x_row_stride = gx.row_stride * es;
+    p.x_pix_stride = gx.pix_stride * es;
+    p.x_origin = (long long)gx.origin * es;
+    p.y = (char*)y->ptr;
+    p.y_img_stride = gy.img_stride * es;
+    p.y_row_stride = gy.row_stride * es;
+    p.y_pix_stride = gy.pix_stride * es;
+    p.y_origin = (long long)gy.origin * es;
+    p.H = x_small ? x->H : y->H;
+    p.W = x_small ? x->W : y->W;
+    p.G = C / 8;
+    p.total = (long long)N * p.H * p.W * p.G;
+    return YOLO_OK;
+}
+
+extern "C" int yolo_dilate2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream) {
+    if (int e = check_slice(x, C, "dilate2x")) return e;
+    if (int e = check_slice(y, C, "dilate2x")) return e;
+    YOLO_REQUIRE(y->H == 2 * x->H && y->W == 2 * x->W, "dilate2x: output must be 2x the input");
+    MoveParams p{};
+    move_common(p, x, y, N, C, (int)elem_size(dtype), true);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((dilate2x_kernel<unsigned short>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((dilate2x_kernel<float>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+extern "C" int yolo_sum2x2_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream) {
+    if (int e = check_slice(x, C, "sum2x2")) return e;
+    if (int e = check_slice(y, C, "sum2x2")) return e;
+    YOLO_REQUIRE(x->H == 2 * y->H && x->W == 2 * y->W, "sum2x2: input must be 2x the output");
+    MoveParams p{};
+    move_common(p, x, y, N, C, (int)elem_size(dtype), false);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((sum2x2_kernel<unsigned short>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((sum2x2_kernel<float>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}

@@ -1,0 +1,255 @@
+// Weight gradient of the convolutions for gfx950, bf16 operands, fp32 result:
+//   dW[co][kh][kw][ci] = sum over (n, ho, wo) of dz[n][ho][wo][co] * x[n][ho*s + kh - pad][wo*s + kw - pad][ci]
+// This is what autograd computes for F.conv2d's weight inside detectron2's Conv2d.forward (the convs built at
+// yolo/modeling/backbone/darknet.py:45-53,74-106 and fpn.py:23-30,44-61,78-92) during the reference's
+// training step (tools/train_net.py -> DefaultTrainer -> losses.backward()).
+//
+// GEMM view per tap: D[co][ci] = sum_k A[co][k] * B[k][ci] with k = output pixel.  Both operands are stored
+// pixel-major (NHWC), i.e. k is the SLOW index of both, the opposite of what an MFMA operand register wants
+// (8 consecutive k per lane).  The tiles are therefore staged as they lie in memory -- [32 pixels][128
+// channels] rows of 256 bytes, LDS-DMA, 16 bytes per lane -- and read with ds_read_b64_tr_b16, which hands
+// each lane one column (channel) of a 4-row (pixel) block: two such reads are one 16x16x32 operand.
+// 16-byte chunk c of row r sits at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3)) (source-side swizzle, same
+// involution on the read): conflict-free transposed reads.
+//
+// Work split: one workgroup = one 128(co) x 128(ci) tile of one tap over one contiguous range of pixels
+// (split-K); partial tiles go to fp32 slabs, a second kernel adds the slabs.  Rows past the end of the pixel
+// range are fetched from a zero pixel of dz's halo, so they add nothing.
+#include "common.h"
+
+namespace yolo {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    const char* x;
+    const char* dz;
+    long long x_img_stride, x_origin, dz_img_stride, dz_origin;  // bytes; x_origin already shifted by -pad
+    int x_row_stride, x_pix_stride, dz_row_stride, dz_pix_stride;  // bytes
+    long long dz_zero;  // byte offset of 256 readable zero bytes... of a zero pixel inside dz's buffer
+    int Ho, Wo, HoWo, stride, ksize, taps;
+    int M;  // N*Ho*Wo
+    float inv_HoWo, inv_Wo;
+    int Cin, Cout, n_mt, n_nt, splits, steps_per_split;
+    float* out;  // [splits][Cout][taps][Cin]
+    long long slab;  // elements per split
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// q = m / d, r = m % d for 0 <= m < 2^24 through a float reciprocal and one correction step
+__device__ __forceinline__ void divmod(int m, int d, float inv, int& q, int& r) {
+    q = (int)((float)m * inv);
+    r = m - q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    } else if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 8 KiB + B 8 KiB)
+    constexpr int TILE = 32 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    int id = blockIdx.x;
+    const int nt = id % p.n_nt;
+    id /= p.n_nt;
+    const int mt = id % p.n_mt;
+    id /= p.n_mt;
+    const int tap = id % p.taps;
+    const int split = id / p.taps;
+    const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
+
+    // ---- loader role: rows (4*wave + g) and +16 of the tile, 16-byte slot l15 of the row
+    const int row0 = 4 * wave + g;
+    const int chunk = l15 ^ swz(row0);  // swz(row0 + 16) == swz(row0)
+    // channels past the end of a slice are fetched from chunk 0: finite values that only reach discarded outputs
+    const int a_ch = mt * 128 + chunk * 8 < p.Cout ? mt * 128 + chunk * 8 : 0;
+    const int b_ch = nt * 128 + chunk * 8 < p.Cin ? nt * 128 + chunk * 8 : 0;
+    const long long x_tap = (long long)kh * p.x_row_stride + (long long)kw * p.x_pix_stride;
+    const int m_begin = split * p.steps_per_split * 32;
+    int m_end = m_begin + p.steps_per_split * 32;
+    if (m_end > p.M) m_end = p.M;
+    const int nsteps = (m_end - m_begin + 31) / 32;
+
+    auto stage = [&](int step, char* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m_begin + step * 32 + row0 + 16 * j;
+            const bool ok = m < m_end;
+            int n, r, ho, wo;
+            divmod(ok ? m : 0, p.HoWo, p.inv_HoWo, n, r);
+            divmod(r, p.Wo, p.inv_Wo, ho, wo);
+            const char* a = ok ? p.dz + p.dz_origin + n * p.dz_img_stride + (long long)ho * p.dz_row_stride +
+                                     (long long)wo * p.dz_pix_stride + a_ch * 2
+                               : p.dz + p.dz_zero + (a_ch & 127) * 2;
+            const char* b = p.x + p.x_origin + n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
+                            (long long)(wo * p.stride) * p.x_pix_stride + x_tap + b_ch * 2;
+            char* la = buf + (16 * j + 4 * wave) * 256;  // wave-uniform base; the DMA adds lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                             (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b,
+                                             (__attribute__((address_space(3))) void*)(la + TILE), 16, 0, 0);
+        }
+    };
+
+    // ---- consumer role: wave = 64 (co) x 64 (ci); transposed-read addresses (tile-independent)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q4 = l15 >> 2, p4 = l15 & 3;
+    int a_off[2][4], b_off[2][4];  // [half of the 8 k rows][fragment]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 8 * g + 4 * h + q4;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int ca = wm * 8 + f * 2 + (p4 >> 1), cb = wn * 8 + f * 2 + (p4 >> 1);
+            a_off[h][f] = 256 * r + 16 * (ca ^ swz(r)) + 8 * (p4 & 1);
+            b_off[h][f] = TILE + 256 * r + 16 * (cb ^ swz(r)) + 8 * (p4 & 1);
+        }
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto frag = [&](const char* buf, const int off[2][4], int f) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(buf + off[0][f]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(buf + off[1][f]));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    if (nsteps > 0) stage(0, smem);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) stage(s + 1, smem + ((s + 1) & 1) * 2 * TILE);
+        const char* buf = smem + (s & 1) * 2 * TILE;
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) a[f] = frag(buf, a_off, f);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) b[f] = frag(buf, b_off, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- partial tile -> this split's slab
+    float* out = p.out + (long long)split * p.slab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = nt * 128 + wn * 64 + j * 16 + l15;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = mt * 128 + wm * 64 + i * 16 + 4 * g + e;
+                if (co < p.Cout && ci < p.Cin) out[((long long)co * p.taps + tap) * p.Cin + ci] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slabs, float* dw, long long n, int splits,
+                                                           int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+        dw[i] = s;
+    }
+}
+
+static void wgrad_plan(int M, int Cin, int Cout, int k, int* n_mt, int* n_nt, int* splits, int* steps_per_split) {
+    *n_mt = (Cout + 127) / 128;
+    *n_nt = (Cin + 127) / 128;
+    const int tiles = *n_mt * *n_nt * k * k;
+    const int steps = (M + 31) / 32;
+    int s = (1024 + tiles - 1) / tiles;  // ~2 rounds of 512 resident workgroups
+    if (s > steps) s = steps;
+    if (s < 1) s = 1;
+    *steps_per_split = (steps + s - 1) / s;
+    *splits = (steps + *steps_per_split - 1) / *steps_per_split;
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k) {
+    if (M <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
+    int n_mt, n_nt, splits, sps;
+    wgrad_plan(M, Cin, Cout, k, &n_mt, &n_nt, &splits, &sps);
+    return (size_t)splits * Cout * k * k * Cin * sizeof(float);
+}
+
+extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N, int Cin, int Cout, int k, int stride,
+                                 float* dw, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    YOLO_REQUIRE(x && dz && x->ptr && dz->ptr && dw && workspace, "conv2d_wgrad: null argument");
+    YOLO_REQUIRE(k == 1 || k == 3, "conv2d_wgrad: kernel size %d (1 or 3)", k);
+    YOLO_REQUIRE(stride == 1 || stride == 2, "conv2d_wgrad: stride %d (1 or 2)", stride);
+    YOLO_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0, "conv2d_wgrad: N/Cin/Cout (Cin %% 8 == 0)");
+    const int pad = (k - 1) / 2;
+    YOLO_REQUIRE(x->halo >= pad, "conv2d_wgrad: input halo %d < pad %d", x->halo, pad);
+    const int Ho = (x->H + 2 * pad - k) / stride + 1, Wo = (x->W + 2 * pad - k) / stride + 1;
+    YOLO_REQUIRE(dz->H == Ho && dz->W == Wo, "conv2d_wgrad: dz view %dx%d, expected %dx%d", dz->H, dz->W, Ho, Wo);
+    YOLO_REQUIRE(x->ch_offset % 8 == 0 && x->ch_total % 8 == 0 && x->ch_offset + Cin <= x->ch_total,
+                 "conv2d_wgrad: bad input channel slice");
+    const int Cout8 = (Cout + 7) / 8 * 8;
+    YOLO_REQUIRE(dz->ch_offset % 8 == 0 && dz->ch_total % 8 == 0 && dz->ch_offset + Cout8 <= dz->ch_total,
+                 "conv2d_wgrad: bad dz channel slice");
+    const long long M = (long long)N * Ho * Wo;
+    YOLO_REQUIRE(M < (1 << 24), "conv2d_wgrad: %lld output pixels (limit 2^24)", M);
+    YOLO_REQUIRE(dz->halo >= 1 || M % 32 == 0, "conv2d_wgrad: dz needs a zero halo when N*Ho*Wo is not a multiple of 32");
+    // a tile row is 128 channels: reads past a narrower slice stay inside the buffer only with rows to spare
+    YOLO_REQUIRE(dz->ch_total >= 128 || dz->halo >= 1, "conv2d_wgrad: dz narrower than 128 channels needs a halo");
+    YOLO_REQUIRE(x->ch_total >= 128 || x->halo >= 1, "conv2d_wgrad: x narrower than 128 channels needs a halo");
+    const ViewGeom gx = geom_of(*x), gd = geom_of(*dz);
+    WgradParams p{};
+    p.x = (const char*)x->ptr;
+    p.dz = (const char*)dz->ptr;
+    p.x_img_stride = gx.img_stride * 2;
+    p.x_row_stride = gx.row_stride * 2;
+    p.x_pix_stride = gx.pix_stride * 2;
+    p.x_origin = ((long long)gx.origin - (long long)pad * gx.row_stride - (long long)pad * gx.pix_stride) * 2;
+    p.dz_img_stride = gd.img_stride * 2;
+    p.dz_row_stride = gd.row_stride * 2;
+    p.dz_pix_stride = gd.pix_stride * 2;
+    p.dz_origin = (long long)gd.origin * 2;
+    p.dz_zero = 0;  // buffer pixel (0,0) of image 0: a halo pixel when halo >= 1 (unused when M % 32 == 0)
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.HoWo = Ho * Wo;
+    p.stride = stride;
+    p.ksize = k;
+    p.taps = k * k;
+    p.M = (int)M;
+    p.inv_HoWo = 1.0f / (float)(Ho * Wo);
+    p.inv_Wo = 1.0f / (float)Wo;
+    p.Cin = Cin;
+    p.Cout = Cout;
+    wgrad_plan((int)M, Cin, Cout, k, &p.n_mt, &p.n_nt, &p.splits, &p.steps_per_split);
+    p.slab = (long long)Cout * k * k * Cin;
+    YOLO_REQUIRE(ws_bytes >= (size_t)p.splits * p.slab * sizeof(float), "conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes,
+                 (size_t)p.splits * p.slab * sizeof(float));
+    p.out = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int LDS = 2 * 2 * 32 * 256;
+    const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), LDS, st, p);
+    long long rb = (p.slab + 255) / 256;
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)workspace, dw, p.slab,
+                       p.splits, accumulate);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}

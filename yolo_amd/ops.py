@@ -328,3 +328,81 @@ def gather_detections(cand: Candidates, keep: torch.Tensor, n_keep: torch.Tensor
                                         _ptr(in_hw), _ptr(out_hw), _ptr(det), _ptr(n_det), _stream())
     check(code, "yolo_gather_detections")
     return det, n_det
+
+
+# --------------------------------------------------------------------------------------
+# training-path operators (batch-statistics BatchNorm + LeakyReLU, conv weight / data gradients)
+# --------------------------------------------------------------------------------------
+def bn_workspace_bytes(N: int, H: int, W: int, C: int) -> int:
+    return int(lib().yolo_bn_workspace_bytes(N, H, W, C))
+
+
+def bn_train_stats(z: View, gamma: torch.Tensor, beta: torch.Tensor, stats: torch.Tensor, workspace: torch.Tensor, *,
+                   eps: float = 1e-5, momentum: float = 0.1, running_mean: Optional[torch.Tensor] = None,
+                   running_var: Optional[torch.Tensor] = None) -> None:
+    """stats [5, C] f32 <- mean, biased var, invstd, scale, shift of z over (N, H, W); updates running stats."""
+    _require_cuda(z.buf, "bn_train_stats")
+    assert stats.dtype == torch.float32 and stats.numel() >= 5 * z.C and stats.is_contiguous()
+    zv = z.c()
+    check(lib().yolo_bn_train_stats(ctypes.byref(zv), z.N, z.C, dtype_code(z.buf.dtype), _ptr(gamma), _ptr(beta),
+                                    float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(stats),
+                                    _ptr(workspace), workspace.numel() * workspace.element_size(), _stream()),
+          "yolo_bn_train_stats")
+
+
+def bn_act_fwd(z: View, stats: torch.Tensor, y: View, *, slope: float = 0.1, residual: Optional[View] = None) -> None:
+    _require_cuda(z.buf, "bn_act_fwd")
+    assert z.buf.dtype == y.buf.dtype
+    zv, yv = z.c(), y.c()
+    rv = residual.c() if residual is not None else None
+    check(lib().yolo_bn_act_fwd(ctypes.byref(zv), _ptr(stats), ctypes.byref(rv) if rv is not None else None,
+                                ctypes.byref(yv), z.N, z.C, float(slope), dtype_code(z.buf.dtype), _stream()),
+          "yolo_bn_act_fwd")
+
+
+def bn_act_bwd(dy: View, z: View, stats: torch.Tensor, dz: View, dgamma: torch.Tensor, dbeta: torch.Tensor,
+               workspace: torch.Tensor, *, slope: float = 0.1) -> None:
+    _require_cuda(z.buf, "bn_act_bwd")
+    assert dy.buf.dtype == z.buf.dtype == dz.buf.dtype
+    assert dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32
+    dyv, zv, dzv = dy.c(), z.c(), dz.c()
+    check(lib().yolo_bn_act_bwd(ctypes.byref(dyv), ctypes.byref(zv), _ptr(stats), ctypes.byref(dzv), z.N, z.C,
+                                float(slope), dtype_code(z.buf.dtype), _ptr(dgamma), _ptr(dbeta), _ptr(workspace),
+                                workspace.numel() * workspace.element_size(), _stream()), "yolo_bn_act_bwd")
+
+
+def wgrad_workspace_bytes(M: int, cin: int, cout: int, k: int) -> int:
+    return int(lib().yolo_conv2d_wgrad_workspace_bytes(M, cin, cout, k))
+
+
+def conv2d_wgrad(x: View, dz: View, dw: torch.Tensor, workspace: torch.Tensor, *, cin: int, cout: int, k: int,
+                 stride: int, accumulate: bool = False) -> None:
+    """dw: f32 [cout, k, k, cin] (the library's layout; ``dw.permute(0, 3, 1, 2)`` is torch's [cout, cin, k, k])."""
+    _require_cuda(x.buf, "conv2d_wgrad")
+    assert x.buf.dtype == torch.bfloat16 and dz.buf.dtype == torch.bfloat16
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * k * k * cin
+    xv, dzv = x.c(), dz.c()
+    check(lib().yolo_conv2d_wgrad(ctypes.byref(xv), ctypes.byref(dzv), x.N, cin, cout, k, stride, _ptr(dw),
+                                  int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                  _stream()), "yolo_conv2d_wgrad")
+
+
+def pack_conv_dgrad(weight: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Packed weights that make yolo_conv2d_fwd compute the DATA gradient of a conv with ``weight``
+    [Cout, Cin, k, k]: channels swapped and taps rotated by 180 degrees, zero bias."""
+    wt = weight.detach().float().flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin, Cout, k, k]
+    return pack_conv(wt, torch.zeros(wt.shape[0]), dtype, device)
+
+
+def dilate2x(x: View, y: View) -> None:
+    _require_cuda(x.buf, "dilate2x")
+    xv, yv = x.c(), y.c()
+    check(lib().yolo_dilate2x_nhwc(ctypes.byref(xv), ctypes.byref(yv), x.N, x.C, dtype_code(x.buf.dtype), _stream()),
+          "yolo_dilate2x_nhwc")
+
+
+def sum2x2(x: View, y: View) -> None:
+    _require_cuda(x.buf, "sum2x2")
+    xv, yv = x.c(), y.c()
+    check(lib().yolo_sum2x2_nhwc(ctypes.byref(xv), ctypes.byref(yv), x.N, x.C, dtype_code(x.buf.dtype), _stream()),
+          "yolo_sum2x2_nhwc")
