@@ -42,7 +42,8 @@ def frozen_names(freeze_at: int, blocks=(1, 2, 8, 8, 4), prefix: str = "backbone
     return names
 
 
-def conv_unit_train(x, sd, name: str, stride: int, pad: int, act: bool, frozen: bool, stats: dict | None = None):
+def conv_unit_train(x, sd, name: str, stride: int, pad: int, act: bool, frozen: bool, stats: dict | None = None,
+                    rec: dict | None = None):
     """detectron2 ``Conv2d.forward`` in training mode: F.conv2d, then BatchNorm2d with BATCH statistics
     (biased variance for the normalisation; running stats updated with momentum 0.1 and the unbiased
     variance), or FrozenBatchNorm2d (running statistics, no update) for frozen blocks; then the
@@ -50,6 +51,7 @@ def conv_unit_train(x, sd, name: str, stride: int, pad: int, act: bool, frozen: 
     w = sd[name + ".weight"]
     b = sd.get(name + ".bias")
     y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    z = y
     if name + ".norm.weight" in sd:
         g, beta = sd[name + ".norm.weight"], sd[name + ".norm.bias"]
         rm, rv = sd[name + ".norm.running_mean"], sd[name + ".norm.running_var"]
@@ -65,16 +67,22 @@ def conv_unit_train(x, sd, name: str, stride: int, pad: int, act: bool, frozen: 
             y = F.batch_norm(y, None, None, g, beta, True, BN_MOMENTUM, R.BN_EPS)
     if act:
         y = F.leaky_relu(y, R.LEAKY)
+    if rec is not None:  # per-layer record (output before any residual add) for layer-by-layer parity checks
+        y.retain_grad()
+        if z.requires_grad:
+            z.retain_grad()
+        rec[name] = dict(x=x, y=y, z=z)
     return y
 
 
-def fpn_forward_train(x, sd, freeze_at: int = 2, prefix="backbone.", blocks=(1, 2, 8, 8, 4), stats: dict | None = None):
+def fpn_forward_train(x, sd, freeze_at: int = 2, prefix="backbone.", blocks=(1, 2, 8, 8, 4), stats: dict | None = None,
+                      rec: dict | None = None):
     """DarkNetFPN.forward (fpn.py:165-185) over DarkNet.forward (darknet.py:203-226) with the modules in
     training mode.  Returns {"p3","p4","p5"} raw head tensors."""
     frozen = set(frozen_names(freeze_at, blocks, prefix))
 
     def cu(t, name, stride, pad, act=True):
-        return conv_unit_train(t, sd, name, stride, pad, act, name in frozen, stats)
+        return conv_unit_train(t, sd, name, stride, pad, act, name in frozen, stats, rec)
 
     x = cu(x, prefix + "bottom_up.stem.conv", 1, 1)
     bu = {}
@@ -87,6 +95,9 @@ def fpn_forward_train(x, sd, freeze_at: int = 2, prefix="backbone.", blocks=(1, 
             out = cu(x, p + ".conv1", 1, 0)
             out = cu(out, p + ".conv2", 1, 1)
             x = out + residual  # :125
+            if rec is not None:
+                x.retain_grad()
+                rec[p + ".conv2"]["out"] = x
         bu[f"res{si}"] = x
     feats = ["res3", "res4", "res5"]
     result, topdown = [], None
@@ -210,10 +221,10 @@ def losses(anchors: torch.Tensor, pred_logits: List[torch.Tensor], pred_confs: L
 def forward_training(x: torch.Tensor, sd: Dict[str, torch.Tensor], gt_boxes: List[torch.Tensor],
                      gt_classes: List[torch.Tensor], num_classes: int, freeze_at: int = 2,
                      anchors_wh=R.DEFAULT_ANCHORS, strides=R.STRIDES, threshold: float = 0.5,
-                     stats: dict | None = None, heads_out: dict | None = None):
+                     stats: dict | None = None, heads_out: dict | None = None, rec: dict | None = None):
     """DenseDetector.forward in training mode -> YOLOV3.forward_training (yolo.py:101-124) on normalised,
     padded images x [N,3,H,W].  Returns the three losses."""
-    heads = fpn_forward_train(x, sd, freeze_at, stats=stats)
+    heads = fpn_forward_train(x, sd, freeze_at, stats=stats, rec=rec)
     feats = [heads["p3"], heads["p4"], heads["p5"]]
     if heads_out is not None:
         heads_out.update(heads)

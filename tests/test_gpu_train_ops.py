@@ -69,21 +69,22 @@ WGRAD_SHAPES = [(64, 128, 3, 1, 9, 7), (128, 64, 1, 1, 9, 7), (64, 128, 3, 2, 14
                 (128, 256, 3, 2, 10, 10), (256, 128, 1, 1, 26, 26)]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("shape", WGRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_conv_wgrad(cuda, shape):
+def test_conv_wgrad(cuda, shape, dtype):
     from yolo_amd import ops
     cin, cout, k, stride, H, W = shape
     g = torch.Generator().manual_seed(cin + 3 * cout + H)
     N = 3
-    x = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    x = torch.randn(N, cin, H, W, generator=g).to(dtype).float()
     w = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
     y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2)
-    dz = torch.randn(y.shape, generator=g).bfloat16().float()
+    dz = torch.randn(y.shape, generator=g).to(dtype).float()
     y.backward(dz)
     Ho, Wo = y.shape[2], y.shape[3]
-    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    xv = ops.view_from_nchw(x.to(cuda), 1, dtype)
     cpad = (cout + 7) // 8 * 8
-    dzv = ops.alloc_view(N, Ho, Wo, cpad, 1, torch.bfloat16, cuda)
+    dzv = ops.alloc_view(N, Ho, Wo, cpad, 1, dtype, cuda)
     dzv.interior()[..., :cout].copy_(dz.to(cuda).permute(0, 2, 3, 1))
     if cpad != cout:
         dzv.interior()[..., cout:] = 7.0  # pad channels must not leak into the result

@@ -45,7 +45,7 @@ SIGNATURES = {
     "yolo_bn_act_fwd": (c_int, [_VP, c_void_p, _VP, _VP, c_int, c_int, c_float, c_int, c_void_p]),
     "yolo_bn_act_bwd": (c_int, [_VP, _VP, c_void_p, _VP, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
-    "yolo_conv2d_wgrad": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
+    "yolo_conv2d_wgrad": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                   c_void_p]),
     "yolo_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "yolo_dilate2x_nhwc": (c_int, [_VP, _VP, c_int, c_int, c_int, c_void_p]),

@@ -1,4 +1,4 @@
-// Weight gradient of the convolutions for gfx950, bf16 operands, fp32 result:
+// Weight gradient of the convolutions for gfx950, bf16 (fast path) or fp32 operands, fp32 result:
 //   dW[co][kh][kw][ci] = sum over (n, ho, wo) of dz[n][ho][wo][co] * x[n][ho*s + kh - pad][wo*s + kw - pad][ci]
 // This is what autograd computes for F.conv2d's weight inside detectron2's Conv2d.forward (the convs built at
 // yolo/modeling/backbone/darknet.py:45-53,74-106 and fpn.py:23-30,44-61,78-92) during the reference's
@@ -160,6 +160,59 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     }
 }
 
+// fp32 operands (the 1e-3 parity plan): plain FMA tiles of 16 x 16 outputs per workgroup, 16 pixels per step
+// through LDS.  Correctness path; the bf16 kernel above is the fast one.
+struct WgradF32Params {
+    const char* x;
+    const char* dz;
+    long long x_img_stride, x_origin, dz_img_stride, dz_origin;  // bytes
+    int x_row_stride, x_pix_stride, dz_row_stride, dz_pix_stride;
+    int Ho, Wo, HoWo, stride, ksize, taps, M, Cin, Cout, splits, pix_per_split;
+    float* out;
+    long long slab;
+};
+
+__global__ void __launch_bounds__(256) wgrad_f32_kernel(const WgradF32Params p) {
+    __shared__ float sa[16][17], sb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+    const int tap = blockIdx.z % p.taps, split = blockIdx.z / p.taps;
+    const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
+    const int m0 = split * p.pix_per_split;
+    const int m1 = m0 + p.pix_per_split < p.M ? m0 + p.pix_per_split : p.M;
+    float acc = 0.f;
+    for (int mb = m0; mb < m1; mb += 16) {
+        const int m = mb + ty;  // this thread stages pixel m: channel tx of both operands
+        float a = 0.f, b = 0.f;
+        if (m < m1) {
+            const int n = m / p.HoWo, r = m - n * p.HoWo, ho = r / p.Wo, wo = r - ho * p.Wo;
+            if (co0 + tx < p.Cout)
+                a = *(const float*)(p.dz + p.dz_origin + n * p.dz_img_stride + (long long)ho * p.dz_row_stride +
+                                    (long long)wo * p.dz_pix_stride + (co0 + tx) * 4);
+            if (ci0 + tx < p.Cin)
+                b = *(const float*)(p.x + p.x_origin + n * p.x_img_stride + (long long)(ho * p.stride + kh) * p.x_row_stride +
+                                    (long long)(wo * p.stride + kw) * p.x_pix_stride + (ci0 + tx) * 4);
+        }
+        sa[ty][tx] = a;
+        sb[ty][tx] = b;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(sa[k][ty], sb[k][tx], acc);
+        __syncthreads();
+    }
+    const int co = co0 + ty, ci = ci0 + tx;
+    if (co < p.Cout && ci < p.Cin) p.out[(long long)split * p.slab + ((long long)co * p.taps + tap) * p.Cin + ci] = acc;
+}
+
+static void wgrad_f32_plan(int M, int Cin, int Cout, int k, int* splits, int* pix_per_split) {
+    const long long tiles = (long long)((Cout + 15) / 16) * ((Cin + 15) / 16) * k * k;
+    long long s = (2048 + tiles - 1) / tiles;
+    if (s > (M + 255) / 256) s = (M + 255) / 256;
+    if (s < 1) s = 1;
+    *pix_per_split = (int)((M + s - 1) / s);
+    *splits = (M + *pix_per_split - 1) / *pix_per_split;
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slabs, float* dw, long long n, int splits,
                                                            int accumulate) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -187,13 +240,54 @@ using namespace yolo;
 
 extern "C" size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k) {
     if (M <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
-    int n_mt, n_nt, splits, sps;
+    int n_mt, n_nt, splits, sps, s32, pps;
     wgrad_plan(M, Cin, Cout, k, &n_mt, &n_nt, &splits, &sps);
+    wgrad_f32_plan(M, Cin, Cout, k, &s32, &pps);
+    if (s32 > splits) splits = s32;
     return (size_t)splits * Cout * k * k * Cin * sizeof(float);
 }
 
+static int wgrad_f32(const yolo_view* x, const yolo_view* dz, int N, int Cin, int Cout, int k, int stride, float* dw,
+                     int accumulate, void* workspace, size_t ws_bytes, hipStream_t st) {
+    const int pad = (k - 1) / 2;
+    const int Ho = dz->H, Wo = dz->W;
+    const ViewGeom gx = geom_of(*x), gd = geom_of(*dz);
+    WgradF32Params p{};
+    p.x = (const char*)x->ptr;
+    p.dz = (const char*)dz->ptr;
+    p.x_img_stride = gx.img_stride * 4;
+    p.x_row_stride = gx.row_stride * 4;
+    p.x_pix_stride = gx.pix_stride * 4;
+    p.x_origin = ((long long)gx.origin - (long long)pad * gx.row_stride - (long long)pad * gx.pix_stride) * 4;
+    p.dz_img_stride = gd.img_stride * 4;
+    p.dz_row_stride = gd.row_stride * 4;
+    p.dz_pix_stride = gd.pix_stride * 4;
+    p.dz_origin = (long long)gd.origin * 4;
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.HoWo = Ho * Wo;
+    p.stride = stride;
+    p.ksize = k;
+    p.taps = k * k;
+    p.M = N * Ho * Wo;
+    p.Cin = Cin;
+    p.Cout = Cout;
+    wgrad_f32_plan(p.M, Cin, Cout, k, &p.splits, &p.pix_per_split);
+    p.slab = (long long)Cout * k * k * Cin;
+    YOLO_REQUIRE(ws_bytes >= (size_t)p.splits * p.slab * sizeof(float), "conv2d_wgrad: workspace too small");
+    YOLO_REQUIRE(p.taps * p.splits <= 65535, "conv2d_wgrad f32: too many splits");
+    p.out = (float*)workspace;
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3((Cin + 15) / 16, (Cout + 15) / 16, p.taps * p.splits), dim3(256), 0, st, p);
+    long long rb = (p.slab + 255) / 256;
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)workspace, dw, p.slab,
+                       p.splits, accumulate);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
 extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N, int Cin, int Cout, int k, int stride,
-                                 float* dw, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+                                 int dtype, float* dw, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     YOLO_REQUIRE(x && dz && x->ptr && dz->ptr && dw && workspace, "conv2d_wgrad: null argument");
     YOLO_REQUIRE(k == 1 || k == 3, "conv2d_wgrad: kernel size %d (1 or 3)", k);
     YOLO_REQUIRE(stride == 1 || stride == 2, "conv2d_wgrad: stride %d (1 or 2)", stride);
@@ -208,7 +302,9 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     YOLO_REQUIRE(dz->ch_offset % 8 == 0 && dz->ch_total % 8 == 0 && dz->ch_offset + Cout8 <= dz->ch_total,
                  "conv2d_wgrad: bad dz channel slice");
     const long long M = (long long)N * Ho * Wo;
+    YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "conv2d_wgrad: dtype %d", dtype);
     YOLO_REQUIRE(M < (1 << 24), "conv2d_wgrad: %lld output pixels (limit 2^24)", M);
+    if (dtype == YOLO_F32) return wgrad_f32(x, dz, N, Cin, Cout, k, stride, dw, accumulate, workspace, ws_bytes, (hipStream_t)stream);
     YOLO_REQUIRE(dz->halo >= 1 || M % 32 == 0, "conv2d_wgrad: dz needs a zero halo when N*Ho*Wo is not a multiple of 32");
     // a tile row is 128 channels: reads past a narrower slice stay inside the buffer only with rows to spare
     YOLO_REQUIRE(dz->ch_total >= 128 || dz->halo >= 1, "conv2d_wgrad: dz narrower than 128 channels needs a halo");

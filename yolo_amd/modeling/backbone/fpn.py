@@ -100,6 +100,8 @@ class DarkNetFPN(Backbone):
         self.head_dtype = torch.float32
         self._engine = None
         self._engine_key = None
+        self._train_engine = None
+        self.freeze_at = 0
 
     @property
     def size_divisibility(self):
@@ -127,17 +129,73 @@ class DarkNetFPN(Backbone):
             self._engine_key = key
         return self._engine
 
+    def train_engine(self):
+        from ...train_engine import TrainEngine
+        if self._train_engine is not None and self._train_engine.dtype != self.compute_dtype:
+            self._train_engine = None
+        if self._train_engine is None:
+            if self._num_classes is None:
+                raise RuntimeError("DarkNetFPN was built without num_classes / anchors; use "
+                                   "build_darknet53_fpn_backbone(cfg, ...)")
+            self._train_engine = TrainEngine(self, num_classes=self._num_classes, num_anchors=len(self._anchors_wh[0]),
+                                             freeze_at=self.freeze_at, blocks=self.bottom_up.blocks_per_stage,
+                                             dtype=self.compute_dtype)
+        return self._train_engine
+
+    def forward_train(self, images: torch.Tensor, mean, std) -> Dict[str, torch.Tensor]:
+        """Training-mode forward on raw images [N,3,Hs,Ws] (0..255, uint8 or float32, on the GPU): batch-statistics
+        BatchNorm in the trainable stages, frozen stages as in inference.  Returns {"p3","p4","p5"} float32 head
+        tensors attached to the autograd graph: ``loss.backward()`` runs the HIP backward plan and leaves the
+        gradients in the parameters' ``.grad``."""
+        eng = self.train_engine()
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        outs = _TrainFunction.apply(eng, images, tuple(mean), tuple(std), [n for n, _ in named], *[p for _, p in named])
+        return dict(zip(self._out_features, outs))
+
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         """x: normalised images [N, 3, H, W] float32 with H, W multiples of 32.  Returns the raw head
         tensors {"p3","p4","p5"} as [N, A*(5+C), H/s, W/s] (strided views of the plan's NHWC buffers; they
         are overwritten by the next call with the same input shape)."""
         if self.training:
-            raise NotImplementedError("training is not built on the HIP path yet; call .eval()")
+            if not x.is_cuda:
+                raise RuntimeError("yolo_amd runs on MI355X only: input is on the CPU and there is no CPU fallback")
+            return self.forward_train(x.float(), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
         if not x.is_cuda:
             raise RuntimeError("yolo_amd runs on MI355X only: input is on the CPU and there is no CPU fallback")
         assert x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0, "H, W must be multiples of size_divisibility (32)"
         P = self.engine().run_backbone(x.float())
         return {k: v.nchw() for k, v in zip(self._out_features, P.heads)}
+
+
+def _frozen(param_name: str, freeze_at: int) -> bool:
+    """freeze_at 1 = stem, 2 = stem + res1, ... (reference darknet.py:245-247)."""
+    if param_name.startswith("bottom_up.stem."):
+        return freeze_at >= 1
+    for si in range(1, 6):
+        if param_name.startswith(f"bottom_up.res{si}."):
+            return freeze_at >= si + 1
+    return False
+
+
+class _TrainFunction(torch.autograd.Function):
+    """The whole backbone + neck as one autograd node: forward and backward are explicit plans of HIP launches
+    (yolo_amd/train_engine.py); torch only sees the trainable parameters going in and the three head tensors
+    coming out."""
+
+    @staticmethod
+    def forward(ctx, eng, images, mean, std, names, *params):
+        heads = eng.forward(images, mean, std)
+        N, _, Hs, Ws = images.shape
+        ctx.eng, ctx.names = eng, names
+        ctx.plan = eng.plan(N, (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
+        return tuple(h.nchw() for h in heads)
+
+    @staticmethod
+    def backward(ctx, *dheads):
+        dheads = [d if d is not None else torch.zeros_like(h.nchw()) for d, h in zip(dheads, ctx.plan.heads)]
+        ctx.eng.backward(ctx.plan, dheads)
+        g = ctx.eng.param_grads(ctx.plan)
+        return (None, None, None, None, None) + tuple(g.get(n) for n in ctx.names)
 
 
 @BACKBONE_REGISTRY.register()
@@ -152,6 +210,10 @@ def build_darknet53_fpn_backbone(cfg, input_shape):
     out_channels = (4 + 1 + num_classes) * num_anchors[0]
     fpn = DarkNetFPN(bottom_up, in_features, out_channels, norm=cfg.MODEL.DARKNET.NORM, num_classes=num_classes,
                      anchors_wh=gen.anchors_wh())
+    fpn.freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
+    for name, p in fpn.named_parameters():  # DarkNet.freeze (reference darknet.py:236-258)
+        if _frozen(name, fpn.freeze_at):
+            p.requires_grad_(False)
     hip = cfg.MODEL.get("HIP", None)
     if hip is not None:
         fpn.compute_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[hip.DTYPE]

@@ -14,8 +14,11 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...structures import Boxes, Instances
+import torch.nn.functional as F
+
+from ...structures import Boxes, Instances, pairwise_iou
 from ..box_regression import Box2BoxTransform
+from ..matcher import Matcher
 from ..registry import META_ARCH_REGISTRY, build_anchor_generator, build_backbone
 
 __all__ = ["YOLOV3", "YoloV3Head"]
@@ -67,6 +70,8 @@ class YOLOV3(nn.Module):
         self.obj_weight, self.noobj_weight = 1, 100
         self.matcher_threshold = cfg.MODEL.MATCHER.IGNORE_THRESHOLD
         self.matcher_labels = list(cfg.MODEL.MATCHER.LABELS)
+        self.anchor_matcher = Matcher(threshold=self.matcher_threshold, labels=self.matcher_labels,
+                                      allow_low_quality_matches=False)
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
@@ -104,9 +109,96 @@ class YOLOV3(nn.Module):
 
     def forward(self, batched_inputs: List[Dict]):
         if self.training:
-            raise NotImplementedError(
-                "YOLOV3 training (label assignment, losses, conv backward, DDP) is not built on the HIP path yet")
+            return self.training_step(batched_inputs)
         return self.inference(batched_inputs)
+
+    # ------------------------------------------------------------------------------------------
+    # training (reference yolo.py:101-264 under detectron2's DenseDetector.forward)
+    # ------------------------------------------------------------------------------------------
+    def training_step(self, batched_inputs: List[Dict]) -> Dict[str, torch.Tensor]:
+        """Returns {"confs_loss", "logits_loss", "regression_loss"}; ``sum(losses.values()).backward()`` runs the
+        HIP backward plan of the backbone and neck.  Convolutions, BatchNorm and their gradients are HIP kernels;
+        the head activations, label assignment and the three losses are torch ops on the GPU, as in the reference."""
+        if self.device.type != "cuda":
+            raise RuntimeError("yolo_amd runs on MI355X only (MODEL.DEVICE must be 'cuda'); there is no CPU fallback")
+        assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
+        batch, _ = self._batch_images(batched_inputs)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        feats = self.backbone.forward_train(batch, self._mean, self._std)
+        features = [feats[f] for f in self.head_in_features]
+        predictions = self.head(features)
+        return self.forward_training(batch, features, predictions, gt_instances)
+
+    @staticmethod
+    def _transpose_dense_predictions(predictions, dims_per_anchor: List[int]):
+        """(N, A*K, H, W) -> (N, H*W*A, K) per level and prediction kind (detectron2 DenseDetector)."""
+        res = []
+        for pred, K in zip(predictions, dims_per_anchor):
+            out = []
+            for t in pred:
+                N, _, H, W = t.shape
+                out.append(t.view(N, -1, K, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, K))
+            res.append(out)
+        return res
+
+    def forward_training(self, images, features, predictions, gt_instances):
+        pred_logits, pred_confs, pred_anchor_deltas = self._transpose_dense_predictions(
+            predictions, [self.num_classes, 1, 4])
+        anchors = self.anchor_generator(features)
+        grid_sizes = [f.shape[-2:] for f in features]
+        gt_labels, gt_boxes = self.label_anchors(anchors, gt_instances, grid_sizes)
+        return self.losses(anchors, pred_logits, pred_confs, pred_anchor_deltas, gt_labels, gt_boxes, self._get_strides())
+
+    def losses(self, anchors: List[Boxes], pred_logits, pred_confs, pred_anchor_deltas, gt_labels, gt_boxes, strides):
+        gt_labels = torch.stack(gt_labels)  # [N, R]
+        gt_boxes = torch.stack(gt_boxes)
+        positive_mask = (gt_labels >= 0) & (gt_labels != self.num_classes)
+        negative_mask = gt_labels == self.num_classes
+        self.num_pos_anchors = positive_mask.sum()  # the reference logs this per image (yolo.py:143-144)
+
+        pred_confs = torch.cat(pred_confs, dim=1)
+        confidence_target = torch.zeros_like(pred_confs)
+        confidence_target[positive_mask] = 1
+        confidence_loss = self._compute_confidence_loss(pred_confs, confidence_target, positive_mask, negative_mask)
+
+        pred_logits = torch.cat(pred_logits, dim=1)
+        target = F.one_hot(gt_labels[positive_mask], self.num_classes + 1)[:, :-1].to(pred_logits.dtype)
+        logits_loss = self._compute_logits_loss(pred_logits[positive_mask], target)
+
+        st = torch.tensor(strides, device=self.device)
+        st = st.repeat_interleave(torch.tensor([d.shape[1] for d in pred_anchor_deltas], device=self.device))
+        pred_anchor_deltas = torch.cat(pred_anchor_deltas, dim=1)
+        regression_loss = self._compute_box_regression_loss(pred_anchor_deltas, gt_boxes, anchors, positive_mask, st)
+        return {"confs_loss": confidence_loss, "logits_loss": logits_loss, "regression_loss": regression_loss}
+
+    def _compute_box_regression_loss(self, pred_anchor_deltas, gt_boxes, anchors, positive_mask, strides):
+        target = self.box2box_transform.get_deltas(gt_boxes, anchors, strides)
+        return F.smooth_l1_loss(pred_anchor_deltas[positive_mask], target[positive_mask], reduction="mean")
+
+    def _compute_confidence_loss(self, pred_confs, target, objectness_mask, noobjectness_mask):
+        obj = F.binary_cross_entropy(pred_confs[objectness_mask], target[objectness_mask], reduction="mean")
+        noobj = F.binary_cross_entropy(pred_confs[noobjectness_mask], target[noobjectness_mask], reduction="mean")
+        return obj * self.obj_weight + noobj * self.noobj_weight
+
+    def _compute_logits_loss(self, pred_logits, target):
+        return F.binary_cross_entropy(pred_logits, target, reduction="mean")
+
+    @torch.no_grad()
+    def label_anchors(self, anchors: List[Boxes], gt_instances: List[Instances], grid_sizes):
+        """Per image: label of every anchor (gt class / num_classes = negative / -1 = ignored) and its matched
+        ground-truth box."""
+        anchors = Boxes.cat(anchors)
+        gt_labels, matched_gt_boxes = [], []
+        for gt in gt_instances:
+            mq = pairwise_iou(gt.gt_boxes, anchors)
+            matched_idx, anchor_labels = self.anchor_matcher(mq, anchors, gt.gt_boxes)
+            boxes_i = gt.gt_boxes.tensor[matched_idx]
+            labels_i = gt.gt_classes[matched_idx]
+            labels_i[anchor_labels == 0] = self.num_classes
+            labels_i[anchor_labels == -1] = -1
+            gt_labels.append(labels_i)
+            matched_gt_boxes.append(boxes_i)
+        return gt_labels, matched_gt_boxes
 
     @torch.no_grad()
     def inference(self, batched_inputs: List[Dict]):

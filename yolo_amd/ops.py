@@ -379,10 +379,11 @@ def conv2d_wgrad(x: View, dz: View, dw: torch.Tensor, workspace: torch.Tensor, *
                  stride: int, accumulate: bool = False) -> None:
     """dw: f32 [cout, k, k, cin] (the library's layout; ``dw.permute(0, 3, 1, 2)`` is torch's [cout, cin, k, k])."""
     _require_cuda(x.buf, "conv2d_wgrad")
-    assert x.buf.dtype == torch.bfloat16 and dz.buf.dtype == torch.bfloat16
+    assert x.buf.dtype == dz.buf.dtype
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * k * k * cin
     xv, dzv = x.c(), dz.c()
-    check(lib().yolo_conv2d_wgrad(ctypes.byref(xv), ctypes.byref(dzv), x.N, cin, cout, k, stride, _ptr(dw),
+    check(lib().yolo_conv2d_wgrad(ctypes.byref(xv), ctypes.byref(dzv), x.N, cin, cout, k, stride,
+                                  dtype_code(x.buf.dtype), _ptr(dw),
                                   int(accumulate), _ptr(workspace), workspace.numel() * workspace.element_size(),
                                   _stream()), "yolo_conv2d_wgrad")
 

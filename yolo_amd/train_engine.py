@@ -1,0 +1,363 @@
+"""Training step of Darknet-53 + FPN as an explicit forward / backward plan of gfx950 kernel launches.
+
+What the reference runs through torch autograd (tools/train_net.py -> detectron2 DefaultTrainer:
+``losses = model(data); losses.backward()`` over yolo/modeling/backbone/darknet.py:113-126,203-226 and
+fpn.py:33-37,66-71,96-100,165-185 with the modules in training mode) is laid out here once per batch shape:
+
+  forward, per trainable conv:   yolo_conv2d_fwd (raw weights, linear)  ->  z
+                                 yolo_bn_train_stats(z) (+ running-stat update)
+                                 yolo_bn_act_fwd(z) (+ residual)         ->  y      [heads: conv + bias only]
+  backward, in reverse order:    yolo_bn_act_bwd(dy, z)                  ->  dz, dgamma, dbeta
+                                 yolo_conv2d_wgrad(x, dz)                ->  dW
+                                 yolo_conv2d_fwd(dz [dilated for stride 2], W^T rot180) (+ other consumers'
+                                 gradient as the fused residual term)    ->  dx
+
+Frozen stages (cfg.MODEL.BACKBONE.FREEZE_AT, darknet.py:236-258: FrozenBatchNorm, no gradients) run as the
+fused inference kernels and take no part in the backward pass.  Activations are bf16 NHWC with a zero halo;
+every activation that backward needs has its own buffer (nothing is recomputed); weight, gamma and beta
+gradients are fp32.  nn.Upsample + torch.cat stay free in forward (channel slices of one buffer); their
+backward is a channel slice of the gradient buffer plus one 2x2-sum kernel.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import View
+
+LEAKY = 0.1
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+@dataclass
+class TLayer:
+    name: str
+    conv: object
+    x: View
+    y: View                      # post-activation output (head: the f32 head tensor)
+    z: Optional[View] = None     # conv output before BatchNorm (trainable BN layers)
+    residual: Optional[View] = None
+    frozen: bool = False
+    slope: float = LEAKY
+    up_dst: Optional[View] = None     # forward: y is also written 2x-upsampled here
+    dy: Optional[View] = None         # gradient w.r.t. y
+    dz: Optional[View] = None         # gradient w.r.t. z (heads: bf16 copy of the head gradient)
+    dzd: Optional[View] = None        # stride 2: dz with zeros inserted
+    dx: Optional[View] = None         # where the data gradient goes (None: not needed)
+    dx_add: Optional[View] = None     # second term of dx (the skip connection's gradient)
+    dx_accumulate: bool = False       # dx already holds another consumer's gradient
+    up_src: Optional[View] = None     # backward: dy = 2x2 sums of this
+    stats: Optional[torch.Tensor] = None
+    dW: Optional[torch.Tensor] = None
+    dgamma: Optional[torch.Tensor] = None
+    dbeta: Optional[torch.Tensor] = None
+    dbias: Optional[torch.Tensor] = None
+
+
+@dataclass
+class TPlan:
+    N: int
+    H: int
+    W: int
+    layers: List[TLayer] = field(default_factory=list)
+    heads: List[View] = field(default_factory=list)       # p3, p4, p5 (f32, 8-padded channels)
+    dheads: List[View] = field(default_factory=list)      # bf16 gradient buffers of the heads
+    prefix: List[Callable] = field(default_factory=list)  # frozen fused launches after the stem
+    stem_y: Optional[View] = None
+    stem_out: Optional[View] = None
+    bn_ws: Optional[torch.Tensor] = None
+    wg_ws: Optional[torch.Tensor] = None
+
+
+class TrainEngine:
+    def __init__(self, backbone, *, num_classes: int, num_anchors: int, freeze_at: int = 2,
+                 blocks: Sequence[int] = (1, 2, 8, 8, 4), dtype: torch.dtype = torch.bfloat16):
+        self.backbone = backbone
+        self.num_classes, self.num_anchors = num_classes, num_anchors
+        self.blocks = list(blocks)
+        self.freeze_at = freeze_at
+        self.device = next(backbone.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("TrainEngine needs the model on an MI355X (cuda device); there is no CPU path")
+        if freeze_at < 2:
+            raise NotImplementedError(
+                "training the stem / first stage (MODEL.BACKBONE.FREEZE_AT < 2) is not built: the 3-channel stem "
+                "has no weight-gradient kernel; the reference's configs freeze both (defaults.py: FREEZE_AT = 2)")
+        self.dtype = dtype  # bf16: the fast path; f32: the 1e-3 parity plan (unfused prefix, FMA weight gradient)
+        self.convs = dict(backbone.darknet_modules())
+        self.frozen = set()
+        names = ["bottom_up.stem.conv"] if freeze_at >= 1 else []
+        for si, nb in enumerate(self.blocks, start=1):
+            if freeze_at >= si + 1:
+                for b in range(nb):
+                    p = f"bottom_up.res{si}.{b}"
+                    names += ([p + ".downsample"] if b == 0 else []) + [p + ".conv1", p + ".conv2"]
+        self.frozen.update(names)
+        self._plans: Dict[Tuple[int, int, int], TPlan] = {}
+        self._wcache: Dict[str, tuple] = {}
+        self._zero_bias: Dict[int, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ packing (weights change every step)
+    def _zeros(self, n: int) -> torch.Tensor:
+        if n not in self._zero_bias:
+            self._zero_bias[n] = torch.zeros(n, device=self.device)
+        return self._zero_bias[n]
+
+    def _packed(self, name: str, kind: str):
+        conv = self.convs[name]
+        ver = (conv.weight._version, None if conv.bias is None else conv.bias._version,
+               None if conv.norm is None else tuple(t._version for t in conv.norm.as_dict().values()))
+        key = (name, kind)
+        hit = self._wcache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        if kind == "folded":       # frozen layer: eval BatchNorm folded in
+            w, b = conv.folded()
+            pw, pb = (ops.pack_stem(w, b, self.device) if conv.in_channels == 3
+                      else ops.pack_conv(w, b, self.dtype, self.device))
+        elif kind == "raw":        # trainable layer: the bare convolution (+ bias for the heads)
+            b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=self.device)
+            pw, pb = ops.pack_conv(conv.weight.detach().float(), b, self.dtype, self.device)
+        else:                      # "dgrad": Cin <-> Cout, taps rotated; Cout padded to what the kernel reads
+            w = conv.weight.detach().float()
+            cpad = (conv.out_channels + 63) // 64 * 64
+            if cpad != conv.out_channels:
+                w = torch.cat([w, w.new_zeros(cpad - conv.out_channels, *w.shape[1:])], 0)
+            pw, pb = ops.pack_conv_dgrad(w, self.dtype, self.device)
+        self._wcache[key] = (ver, pw, pb)
+        return pw, pb
+
+    # ------------------------------------------------------------------ plan
+    def plan(self, N: int, H: int, W: int) -> TPlan:
+        key = (N, H, W)
+        if key not in self._plans:
+            self._plans[key] = self._build(N, H, W)
+        return self._plans[key]
+
+    def _build(self, N: int, H: int, W: int) -> TPlan:
+        assert H % 32 == 0 and W % 32 == 0
+        dt, dev = self.dtype, self.device
+        P = TPlan(N, H, W)
+        A = lambda h, w, c, halo=1, dtype=dt: ops.alloc_view(N, h, w, c, halo, dtype, dev)  # noqa: E731
+        written = set()  # ids of gradient buffers that already hold a consumer's contribution
+
+        def add(name, x, y, *, residual=None, slope=LEAKY, dy=None, up_dst=None, up_src=None):
+            conv = self.convs[name]
+            L = TLayer(name, conv, x, y, residual=residual, slope=slope, frozen=name in self.frozen,
+                       up_dst=up_dst, up_src=up_src, dy=dy)
+            if not L.frozen:
+                ho, wo = y.H, y.W
+                if conv.norm is not None:
+                    L.z = A(ho, wo, conv.out_channels, 0)
+                    L.stats = torch.zeros(5, conv.out_channels, device=dev)
+                    L.dgamma = torch.zeros(conv.out_channels, device=dev)
+                    L.dbeta = torch.zeros(conv.out_channels, device=dev)
+                    L.dz = A(ho, wo, conv.out_channels)
+                else:
+                    L.dbias = torch.zeros(conv.out_channels, device=dev)
+                if conv.stride == 2:
+                    L.dzd = A(2 * ho, 2 * wo, conv.out_channels)
+                L.dW = torch.zeros(conv.out_channels, conv.kernel_size, conv.kernel_size, conv.in_channels, device=dev)
+            P.layers.append(L)
+            return L
+
+        grads: Dict[int, View] = {}  # activation buffer id -> gradient view of the same geometry
+
+        def grad_of(v: View) -> View:
+            """Gradient view matching activation view ``v`` (same buffer geometry and channel slice)."""
+            k = id(v.buf)
+            if k not in grads:
+                grads[k] = View(torch.zeros_like(v.buf), v.H, v.W, v.halo, v.buf.shape[3], 0)
+            gb = grads[k]
+            return View(gb.buf, v.H, v.W, v.halo, v.C, v.ch_offset)
+
+        # ---- forward topology (mirrors yolo_amd/engine.py)
+        stem = self.convs["bottom_up.stem.conv"]
+        c1 = self.convs["bottom_up.res1.0.downsample"].out_channels
+        chans = [c1 * 2 ** i for i in range(5)]
+        cat = {3: A(H // 8, W // 8, chans[2] + chans[2] // 2), 4: A(H // 16, W // 16, chans[3] + chans[3] // 2)}
+        h, w = H, W
+        fused_prefix = (dt == torch.bfloat16 and stem.out_channels == 32 and c1 == 64 and self.blocks[0] >= 1
+                        and self.freeze_at >= 2)
+        x = None
+        stage_out: Dict[int, View] = {}
+        if not fused_prefix:
+            P.stem_out = A(H, W, stem.out_channels)
+            x = P.stem_out
+        for si, nb in enumerate(self.blocks, start=1):
+            h, w = h // 2, w // 2
+            co = chans[si - 1]
+            if si == 1 and fused_prefix:
+                X, X2 = A(h, w, co), A(h, w, co)
+                P.stem_y = X
+                for b in range(nb):
+                    p = f"bottom_up.res1.{b}"
+                    P.prefix.append(lambda p=p, a=X, o=X2: ops.resblock_c64_fwd(
+                        a, *self._packed(p + ".conv1", "folded"), *self._packed(p + ".conv2", "folded"), o))
+                    X, X2 = X2, X
+            else:
+                X = A(h, w, co)
+                add(f"bottom_up.res{si}.0.downsample", x, X)
+                for b in range(nb):
+                    p = f"bottom_up.res{si}.{b}"
+                    T = A(h, w, co // 2)
+                    add(p + ".conv1", X, T)
+                    last = b == nb - 1
+                    Y = cat[si].slice(co // 2, co) if (last and si in cat) else A(h, w, co)
+                    add(p + ".conv2", T, Y, residual=X)
+                    X = Y
+            stage_out[si] = X
+            x = X
+        ak = (5 + self.num_classes) * self.num_anchors
+        ak_pad = (ak + 7) // 8 * 8
+        feats = [stage_out[5], cat[4], cat[3]]
+        heads, dheads = [], []
+        for idx in range(3):
+            f = feats[idx]
+            lat = self.convs[f"fpn_lateral{idx}.blocks.0"].out_channels
+            fh, fw = f.H, f.W
+            src = f
+            for i in range(5):
+                dst = A(fh, fw, lat if i % 2 == 0 else lat * 2)
+                add(f"fpn_lateral{idx}.blocks.{i}", src, dst)
+                src = dst
+            lat_out = src
+            B = A(fh, fw, lat * 2)
+            add(f"fpn_output{idx}.conv", lat_out, B)
+            hv = A(fh, fw, ak_pad, 0, torch.float32)
+            L = add(f"fpn_output{idx}.head", B, View(hv.buf, fh, fw, 0, ak_pad, 0), slope=1.0)
+            L.dz = A(fh, fw, (ak + 63) // 64 * 64)  # bf16 copy of the head gradient, padded for the dgrad conv
+            heads.insert(0, View(hv.buf, fh, fw, 0, ak, 0))
+            dheads.insert(0, L.dz)
+            if idx < 2:
+                up_c = self.convs[f"fpn_upsample{idx}.conv"].out_channels
+                t = A(fh, fw, up_c)
+                add(f"fpn_upsample{idx}.conv", lat_out, t, up_dst=cat[4 - idx].slice(0, up_c))
+        P.heads, P.dheads = heads, dheads
+
+        # ---- backward wiring: walk the layers in reverse and decide where each data gradient lands
+        first_trainable = next(i for i, L in enumerate(P.layers) if not L.frozen)
+        for i in range(len(P.layers) - 1, -1, -1):
+            L = P.layers[i]
+            if L.frozen:
+                continue
+            if L.conv.norm is not None:
+                if L.up_dst is not None:   # gradient arrives through the 2x upsample into the concat buffer
+                    L.up_src = grad_of(L.up_dst)
+                    L.dy = View(torch.zeros_like(L.y.buf), L.y.H, L.y.W, L.y.halo, L.y.C, 0)
+                else:
+                    L.dy = grad_of(L.y)
+            if i == first_trainable or self._producer_frozen(P, L):
+                continue                   # its input comes from frozen layers: no data gradient
+            L.dx = grad_of(L.x)
+            kx = id(L.dx.buf)
+            if L.residual is None and self._is_conv1(L):
+                pass
+            if self._is_conv1(L):          # block input also feeds the skip connection: + d(block output)
+                blk_out = P.layers[i + 1]
+                assert blk_out.residual is not None and blk_out.residual.buf is L.x.buf
+                assert kx not in written, "block input with a third consumer"
+                L.dx_add = grad_of(blk_out.y)
+            elif kx in written:
+                L.dx_accumulate = True
+            written.add(kx)
+        n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
+        P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
+        n_wg = max(ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
+                                             L.conv.kernel_size) for L in P.layers if not L.frozen)
+        P.wg_ws = torch.empty(n_wg, dtype=torch.uint8, device=dev)
+        return P
+
+    @staticmethod
+    def _is_conv1(L: TLayer) -> bool:
+        return L.name.endswith(".conv1") and ".res" in L.name
+
+    def _producer_frozen(self, P: TPlan, L: TLayer) -> bool:
+        for M in P.layers:
+            if M.y.buf is L.x.buf and M is not L:
+                return M.frozen
+        return True  # produced by the fused frozen prefix
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images: torch.Tensor, mean, std, *, update_running_stats: bool = True) -> List[View]:
+        """images [N,3,Hs,Ws] uint8/float32 (0..255) on the GPU; returns the head views p3, p4, p5 (f32 NHWC)."""
+        N, _, Hs, Ws = images.shape
+        P = self.plan(N, (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
+        stem_w, stem_b = self._packed("bottom_up.stem.conv", "folded")
+        if P.stem_y is not None:
+            dw, db = self._packed("bottom_up.res1.0.downsample", "folded")
+            ops.stem_down_fwd(images.contiguous(), stem_w, stem_b, dw, db, P.stem_y, padded_hw=(P.H, P.W), mean=mean, std=std)
+            for step in P.prefix:
+                step()
+        else:
+            ops.stem_fwd(images.contiguous(), stem_w, stem_b, P.stem_out, mean=mean, std=std)
+        for L in P.layers:
+            c = L.conv
+            if L.frozen:
+                w, b = self._packed(L.name, "folded")
+                ops.conv2d_fwd(L.x, w, b, L.y, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride,
+                               slope=L.slope, residual=L.residual)
+                continue
+            w, b = self._packed(L.name, "raw")
+            if c.norm is None:   # linear head with bias
+                ops.conv2d_fwd(L.x, w, b, L.y, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride,
+                               slope=1.0)
+                continue
+            ops.conv2d_fwd(L.x, w, b, L.z, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride, slope=1.0)
+            n = c.norm
+            ops.bn_train_stats(L.z, n.weight.detach(), n.bias.detach(), L.stats, P.bn_ws, eps=n.eps, momentum=BN_MOMENTUM,
+                               running_mean=n.running_mean if update_running_stats else None,
+                               running_var=n.running_var if update_running_stats else None)
+            ops.bn_act_fwd(L.z, L.stats, L.y, slope=L.slope, residual=L.residual)
+            if L.up_dst is not None:
+                ops.upsample2x(L.y, L.up_dst)
+        return P.heads
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P: TPlan, dheads: Sequence[torch.Tensor]) -> None:
+        """dheads: gradients of the loss w.r.t. the head tensors p3, p4, p5 as [N, A*(5+C), G, G] (any strides).
+        Fills L.dW / dgamma / dbeta / dbias of every trainable layer."""
+        ak = (5 + self.num_classes) * self.num_anchors
+        for dv, g in zip(P.dheads, dheads):
+            dv.interior()[..., :ak].copy_(g.permute(0, 2, 3, 1))
+        head_grad = {id(dv.buf): g for dv, g in zip(P.dheads, dheads)}
+        for L in reversed(P.layers):
+            if L.frozen:
+                continue
+            c = L.conv
+            if c.norm is None:
+                L.dbias.copy_(head_grad[id(L.dz.buf)].sum(dim=(0, 2, 3)))
+            else:
+                if L.up_src is not None:
+                    ops.sum2x2(L.up_src, L.dy)
+                ops.bn_act_bwd(L.dy, L.z, L.stats, L.dz, L.dgamma, L.dbeta, P.bn_ws, slope=L.slope)
+            dz = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, (c.out_channels + 7) // 8 * 8, 0)
+            ops.conv2d_wgrad(L.x, dz, L.dW, P.wg_ws, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride)
+            if L.dx is None:
+                continue
+            w, b = self._packed(L.name, "dgrad")
+            cpad = (c.out_channels + 63) // 64 * 64
+            src = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, cpad, 0)
+            if c.stride == 2:
+                ops.dilate2x(src, L.dzd)
+                src = L.dzd
+            res = L.dx_add if L.dx_add is not None else (L.dx if L.dx_accumulate else None)
+            ops.conv2d_fwd(src, w, b, L.dx, cin=cpad, cout=c.in_channels, k=c.kernel_size, stride=1, slope=1.0, residual=res)
+
+    def param_grads(self, P: TPlan) -> Dict[str, torch.Tensor]:
+        """name -> gradient in the parameter's own layout ([Cout, Cin, k, k] views of the f32 buffers)."""
+        out = {}
+        for L in P.layers:
+            if L.frozen:
+                continue
+            out[L.name + ".weight"] = L.dW.permute(0, 3, 1, 2)
+            if L.conv.norm is not None:
+                out[L.name + ".norm.weight"] = L.dgamma
+                out[L.name + ".norm.bias"] = L.dbeta
+            else:
+                out[L.name + ".bias"] = L.dbias
+        return out
