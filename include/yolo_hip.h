@@ -250,6 +250,17 @@ int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N, int Cin, i
                       int dtype, float* dw, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k);
 
+/*
+ * Per-step repacking of a trainable conv's f32 master weights w [Cout][Cin][k][k] (torch layout) into
+ *   w_fwd    rows [co][kh][kw][ci] of `fwd_row` elements (what yolo_conv2d_fwd reads), and/or
+ *   w_dgrad  rows [ci][kh][kw][co] of `dgrad_row` elements, taps rotated by 180 degrees, co padded to Cout_pad
+ *            (what yolo_conv2d_fwd reads when it computes the data gradient);
+ * either may be NULL.  Padding rows/columns are not written: zero the buffers once.  Replaces the
+ * detach/flip/permute/cast chain a torch implementation would run per layer and step.
+ */
+int yolo_pack_conv_train(const float* w, int Cout, int Cin, int k, int dtype, void* w_fwd, int fwd_row,
+                         void* w_dgrad, int dgrad_row, int Cout_pad, void* stream);
+
 /* y[2i][2j] = x[i][j], zeros elsewhere in each 2x2 cell (input of a stride-2 conv's data gradient). */
 int yolo_dilate2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
 /* y[i][j] = sum of the 2x2 cell of x: backward of nn.Upsample(2, "nearest") (fpn.py:31,36). */

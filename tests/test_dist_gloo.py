@@ -61,3 +61,49 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [e - b for b, e in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from yolo_amd.utils import dist as D
+    D.init_from_env("gloo")
+    n = 1000
+    arena = torch.arange(n, dtype=torch.float32) * (rank + 1)  # rank r holds (r+1) * i
+    bk = D.GradBucketer(arena, bucket_bytes=300 * 4)
+    bk.start()
+    for end in (100, 250, 320, 700, 990):   # "layers" finishing during backward
+        bk.ready(end)
+    bk.finish()
+    if rank == 0:
+        out.put((arena.tolist(), bk.launched))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucketer_world2():
+    """Training's only exchange step: bucketed all-reduce (mean) of the flat gradient arena, launched while
+    'backward' is still producing later ranges."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    arena, launched = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert arena == [1.5 * i for i in range(1000)]               # mean of 1*i and 2*i
+    assert launched == [(0, 320), (320, 700), (700, 1000)]        # >= 300 elements per bucket, tail flushed
+
+
+def test_grad_bucketer_single_process_is_a_noop():
+    from yolo_amd.utils.dist import GradBucketer
+    a = torch.ones(10)
+    bk = GradBucketer(a, 16)
+    bk.start()
+    bk.ready(4)
+    bk.ready(8)
+    bk.finish()
+    assert torch.equal(a, torch.ones(10)) and bk.launched == [(0, 4), (4, 8), (8, 10)]

@@ -94,8 +94,8 @@ def test_no_cpu_fallback(model20):
         model20([{"image": torch.zeros(3, 64, 64)}])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model20.backbone(torch.zeros(1, 3, 64, 64))
-    model20.train()
-    with pytest.raises(NotImplementedError):
+    model20.train()   # training runs on the GPU only, too
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         model20([{"image": torch.zeros(3, 64, 64)}])
     model20.eval()
 
@@ -187,7 +187,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
-    assert L.yolo_abi_version() == 3
+    assert L.yolo_abi_version() == 4
     assert L.yolo_conv_cout_pad(255) == 256 and L.yolo_conv_cout_pad(32) == 128
 
 

@@ -88,3 +88,36 @@ def test_frozen_parameters_follow_freeze_at(model_cpu):
     want = {"backbone." + n for n in frozen if n.endswith("conv.weight") or n.endswith(".weight") and ".norm." not in n}
     names = set(T.frozen_names(2))
     assert {w.rsplit(".weight", 1)[0] for w in want} == names
+
+
+def test_solver_schedule_and_groups(model_cpu):
+    """detectron2 defaults the reference trains with: no weight decay on norm parameters, frozen parameters left
+    out, linear warm-up into a multi-step schedule."""
+    from yolo_amd.solver import build_lr_scheduler, build_optimizer
+    model, cfg = model_cpu
+    opt = build_optimizer(cfg, model)
+    g_other, g_norm = opt.param_groups
+    assert g_other["weight_decay"] == cfg.SOLVER.WEIGHT_DECAY and g_norm["weight_decay"] == 0.0
+    n_train = sum(p.requires_grad for p in model.parameters())
+    assert len(g_other["params"]) + len(g_norm["params"]) == n_train == 210
+    sch = build_lr_scheduler(cfg, opt)
+    lrs = []
+    for _ in range(1002):
+        lrs.append(sch.get_last_lr()[0])
+        opt.step()
+        sch.step()
+    base = cfg.SOLVER.BASE_LR
+    assert abs(lrs[0] - base * cfg.SOLVER.WARMUP_FACTOR) < 1e-12
+    assert abs(lrs[500] - base * (0.001 * 0.5 + 0.5)) < 1e-9 and abs(lrs[1001] - base) < 1e-12
+    sch.last_epoch = cfg.SOLVER.STEPS[0]
+    assert abs(sch.get_lr()[0] - base * cfg.SOLVER.GAMMA) < 1e-12
+
+
+def test_training_raises_on_cpu(model_cpu):
+    model, cfg = model_cpu
+    model.train()
+    img = torch.zeros(3, 64, 64, dtype=torch.uint8)
+    inst = Instances((64, 64), gt_boxes=Boxes(torch.tensor([[4., 4., 40., 40.]])), gt_classes=torch.tensor([1]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model([dict(image=img, instances=inst)])
+    model.eval()

@@ -1,10 +1,11 @@
 """Training / evaluation entry point with the reference's flags (tools/train_net.py:117-147 uses
 detectron2's default_argument_parser and launch()).
 
-Status: the HIP path implements inference.  ``--eval-only`` loads the weights and runs image-sharded
-inference over the given inputs, one process per GPU (start N processes with torch.distributed.run; backend
-"nccl" = RCCL).  Training (label assignment, losses, convolution backward, DDP gradient all-reduce) is not
-built yet and raises.
+Training: one process per GPU (start N processes with torch.distributed.run; backend "nccl" = RCCL); every rank
+runs the HIP forward/backward plan on its own images and the gradients are all-reduced in buckets from inside the
+backward pass.  There is no dataset registry offline, so ``--synthetic`` (the default data source) feeds
+COCO-shaped synthetic targets; a real loader plugs in as any iterable of ``list[dict(image, instances)]``.
+``--eval-only`` loads the weights and runs image-sharded inference over ``--input`` images.
 """
 from __future__ import annotations
 
@@ -34,6 +35,10 @@ def default_argument_parser():
     p.add_argument("--machine-rank", type=int, default=0)
     p.add_argument("--dist-url", default="tcp://127.0.0.1:29500")
     p.add_argument("--input", nargs="*", default=[], help="images for --eval-only (no dataset registry offline)")
+    p.add_argument("--synthetic", action="store_true", default=True, help="train on synthetic COCO-shaped targets")
+    p.add_argument("--train-size", type=int, default=416, help="training image side (multiple of 32)")
+    p.add_argument("--multi-scale", action="store_true", help="draw the side per step from 320..608 step 32")
+    p.add_argument("--max-iter", type=int, default=None, help="override SOLVER.MAX_ITER")
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     return p
 
@@ -52,10 +57,17 @@ def main(args):
     if world > 1:
         torch.cuda.set_device(local)
     model = build_model(cfg)
+    if not args.eval_only:
+        from yolo_amd.trainer import Trainer, synthetic_batches
+        per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // world, 1)
+        sizes = list(range(320, 609, 32)) if args.multi_scale else None
+        data = synthetic_batches(cfg, per_gpu, args.train_size, seed=7 + rank, device=model.device, sizes=sizes)
+        trainer = Trainer(cfg, model, data, log=lambda m: print(f"[rank {rank}] {m}") if rank == 0 else None)
+        trainer.resume_or_load(resume=args.resume)
+        trainer.train(max_iter=args.max_iter)
+        return
     ck = YOLOV3Checkpointer(model, cfg.OUTPUT_DIR)
     ck.resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
-    if not args.eval_only:
-        raise NotImplementedError("training is not built on the HIP path yet (inference only); use --eval-only")
     from inference import Predictor, read_image_bgr  # same directory
     model.eval()
     paths = sorted(p for pat in args.input for p in glob.glob(os.path.expanduser(pat)))

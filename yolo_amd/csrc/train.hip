@@ -146,15 +146,27 @@ struct FinParams {
     float* dbeta;
 };
 
-// One thread per channel; partials are folded in double precision.
+// One workgroup per 8 channels: 32 thread groups stride over the partial blocks (double precision), then fold
+// through LDS, so the serial chain per thread is blocks/32 loads instead of blocks.
 template <int MODE>
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const FinParams p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
+    __shared__ double sa[32][8], sb[32][8];
+    const int cl = threadIdx.x & 7, j = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0, b = 0.0;
-    for (int i = 0; i < p.blocks; ++i) {
-        a += (double)p.partial[((long long)i * 2 + 0) * p.C + c];
-        b += (double)p.partial[((long long)i * 2 + 1) * p.C + c];
+    if (c < p.C) {
+        for (int i = j; i < p.blocks; i += 32) {
+            a += (double)p.partial[((long long)i * 2 + 0) * p.C + c];
+            b += (double)p.partial[((long long)i * 2 + 1) * p.C + c];
+        }
+    }
+    sa[j][cl] = a;
+    sb[j][cl] = b;
+    __syncthreads();
+    if (j != 0 || c >= p.C) return;
+    for (int k = 1; k < 32; ++k) {
+        a += sa[k][cl];
+        b += sb[k][cl];
     }
     if constexpr (MODE == 0) {
         const double mean = a / p.count;
@@ -302,7 +314,7 @@ static int check_slice(const yolo_view* v, int C, const char* what) {
 }
 
 static int red_blocks(long long M, int* chunk) {
-    long long c = (M + 2047) / 2048;
+    long long c = (M + 1023) / 1024;
     if (c < 64) c = 64;
     *chunk = (int)c;
     return (int)((M + c - 1) / c);
@@ -363,7 +375,7 @@ extern "C" int yolo_bn_train_stats(const yolo_view* z, int N, int C, int dtype, 
     f.shift = stats + 4 * C;
     f.running_mean = running_mean;
     f.running_var = running_var;
-    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((C + 255) / 256), dim3(256), 0, st, f);
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((C + 7) / 8), dim3(256), 0, st, f);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }
@@ -471,7 +483,7 @@ extern "C" int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const fl
     f.count = (double)r.M;
     f.dgamma = dgamma;
     f.dbeta = dbeta;
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((C + 255) / 256), dim3(256), 0, st, f);
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((C + 7) / 8), dim3(256), 0, st, f);
     ApplyParams p{};
     fill_apply(p, z, dy, dz, N, C, es);
     p.mean = stats;
@@ -535,6 +547,55 @@ extern "C" int yolo_sum2x2_nhwc(const yolo_view* x, const yolo_view* y, int N, i
         hipLaunchKernelGGL((sum2x2_kernel<unsigned short>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((sum2x2_kernel<float>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+namespace yolo {
+
+// Per-step repacking of a trainable convolution's fp32 master weights [Cout][Cin][k][k] into the two operand
+// layouts the kernels read: forward rows [co][kh][kw][ci] and data-gradient rows [ci][kh][kw][co] with the taps
+// rotated by 180 degrees (co padded to CoutP with zeros by the caller's one-time memset).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_train_kernel(const float* w, T* fwd, T* dgrad, int Cout, int Cin, int k,
+                                                         int fwd_row, int dg_row, int CoutP) {
+    const int kk = k * k;
+    const long long n = (long long)Cout * Cin * kk;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        // i enumerates the forward layout (co, t, ci): coalesced writes there
+        const int ci = (int)(i % Cin);
+        const long long r = i / Cin;
+        const int t = (int)(r % kk), co = (int)(r / kk);
+        const float v = w[((long long)co * Cin + ci) * kk + t];
+        T o;
+        if constexpr (sizeof(T) == 2)
+            o = f32_to_bf16_bits(v);
+        else
+            o = v;
+        if (fwd) fwd[(long long)co * fwd_row + t * Cin + ci] = o;
+        if (dgrad) dgrad[(long long)ci * dg_row + (kk - 1 - t) * CoutP + co] = o;
+    }
+}
+
+}  // namespace yolo
+
+extern "C" int yolo_pack_conv_train(const float* w, int Cout, int Cin, int k, int dtype, void* w_fwd, int fwd_row,
+                                    void* w_dgrad, int dgrad_row, int Cout_pad, void* stream) {
+    YOLO_REQUIRE(w && (w_fwd || w_dgrad), "pack_conv_train: null argument");
+    YOLO_REQUIRE(Cout > 0 && Cin > 0 && (k == 1 || k == 3), "pack_conv_train: bad shape");
+    YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "pack_conv_train: dtype %d", dtype);
+    YOLO_REQUIRE((!w_fwd || fwd_row >= k * k * Cin) && (!w_dgrad || (Cout_pad >= Cout && dgrad_row >= k * k * Cout_pad)),
+                 "pack_conv_train: row lengths too short");
+    const long long n = (long long)Cout * Cin * k * k;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((yolo::pack_train_kernel<unsigned short>), dim3((unsigned)blocks), dim3(256), 0, st, w,
+                           (unsigned short*)w_fwd, (unsigned short*)w_dgrad, Cout, Cin, k, fwd_row, dgrad_row, Cout_pad);
+    else
+        hipLaunchKernelGGL((yolo::pack_train_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, (float*)w_fwd,
+                           (float*)w_dgrad, Cout, Cin, k, fwd_row, dgrad_row, Cout_pad);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }

@@ -407,3 +407,18 @@ def sum2x2(x: View, y: View) -> None:
     xv, yv = x.c(), y.c()
     check(lib().yolo_sum2x2_nhwc(ctypes.byref(xv), ctypes.byref(yv), x.N, x.C, dtype_code(x.buf.dtype), _stream()),
           "yolo_sum2x2_nhwc")
+
+
+def pack_conv_train(weight: torch.Tensor, w_fwd: Optional[torch.Tensor], w_dgrad: Optional[torch.Tensor], *,
+                    cout_pad: int) -> None:
+    """One launch: f32 master weights [Cout,Cin,k,k] -> forward and data-gradient operand buffers (2-D, zeroed once
+    by the caller; see pack_conv / pack_conv_dgrad for the layouts)."""
+    _require_cuda(weight, "pack_conv_train")
+    w = weight.detach()
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    cout, cin, k, _ = w.shape
+    ref = w_fwd if w_fwd is not None else w_dgrad
+    check(lib().yolo_pack_conv_train(_ptr(w), cout, cin, k, dtype_code(ref.dtype), _ptr(w_fwd),
+                                     0 if w_fwd is None else w_fwd.shape[1], _ptr(w_dgrad),
+                                     0 if w_dgrad is None else w_dgrad.shape[1], cout_pad, _stream()),
+          "yolo_pack_conv_train")

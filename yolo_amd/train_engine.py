@@ -56,6 +56,7 @@ class TLayer:
     dgamma: Optional[torch.Tensor] = None
     dbeta: Optional[torch.Tensor] = None
     dbias: Optional[torch.Tensor] = None
+    arena_end: int = 0                # end of this layer's gradients inside the plan's arena
 
 
 @dataclass
@@ -71,6 +72,8 @@ class TPlan:
     stem_out: Optional[View] = None
     bn_ws: Optional[torch.Tensor] = None
     wg_ws: Optional[torch.Tensor] = None
+    arena: Optional[torch.Tensor] = None   # all parameter gradients, flat fp32, in backward order
+    bucketer: Optional[object] = None
 
 
 class TrainEngine:
@@ -99,7 +102,10 @@ class TrainEngine:
         self.frozen.update(names)
         self._plans: Dict[Tuple[int, int, int], TPlan] = {}
         self._wcache: Dict[str, tuple] = {}
+        self._wbufs: Dict[str, tuple] = {}
         self._zero_bias: Dict[int, torch.Tensor] = {}
+        self.bucket_bytes = 64 << 20
+        self.process_group = None
 
     # ------------------------------------------------------------------ packing (weights change every step)
     def _zeros(self, n: int) -> torch.Tensor:
@@ -119,15 +125,27 @@ class TrainEngine:
             w, b = conv.folded()
             pw, pb = (ops.pack_stem(w, b, self.device) if conv.in_channels == 3
                       else ops.pack_conv(w, b, self.dtype, self.device))
-        elif kind == "raw":        # trainable layer: the bare convolution (+ bias for the heads)
-            b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=self.device)
-            pw, pb = ops.pack_conv(conv.weight.detach().float(), b, self.dtype, self.device)
-        else:                      # "dgrad": Cin <-> Cout, taps rotated; Cout padded to what the kernel reads
-            w = conv.weight.detach().float()
-            cpad = (conv.out_channels + 63) // 64 * 64
-            if cpad != conv.out_channels:
-                w = torch.cat([w, w.new_zeros(cpad - conv.out_channels, *w.shape[1:])], 0)
-            pw, pb = ops.pack_conv_dgrad(w, self.dtype, self.device)
+        else:
+            # trainable layer: "raw" = the bare convolution (+ bias for the heads); "dgrad" = Cin <-> Cout with the
+            # taps rotated, Cout padded to what the kernel reads.  Both come from ONE repacking launch per step
+            # into buffers allocated (and zero-padded) once.
+            k, cin, cout = conv.kernel_size, conv.in_channels, conv.out_channels
+            cpad = (cout + 63) // 64 * 64
+            bufs = self._wbufs.get(name)
+            if bufs is None:
+                mk = lambda rows, cols: torch.zeros(rows, cols, dtype=self.dtype, device=self.device)  # noqa: E731
+                extra = 32 if (self.dtype == torch.bfloat16 and k == 3) else 0   # a 32-channel row spans two taps
+                bufs = (mk(ops.lib().yolo_conv_cout_pad(cout), k * k * cin + (extra if cin == 32 else 0)),
+                        mk(ops.lib().yolo_conv_cout_pad(cin), k * k * cpad + (extra if cpad == 32 else 0)),
+                        torch.zeros(ops.lib().yolo_conv_cout_pad(cout), device=self.device),
+                        torch.zeros(ops.lib().yolo_conv_cout_pad(cin), device=self.device))
+                self._wbufs[name] = bufs
+            ops.pack_conv_train(conv.weight, bufs[0], bufs[1], cout_pad=cpad)
+            if conv.bias is not None:
+                bufs[2][:cout].copy_(conv.bias.detach())
+            self._wcache[(name, "raw")] = (ver, bufs[0], bufs[2])
+            self._wcache[(name, "dgrad")] = (ver, bufs[1], bufs[3])
+            return self._wcache[key][1], self._wcache[key][2]
         self._wcache[key] = (ver, pw, pb)
         return pw, pb
 
@@ -265,6 +283,25 @@ class TrainEngine:
             elif kx in written:
                 L.dx_accumulate = True
             written.add(kx)
+        # every parameter gradient is a view of one flat arena, in the order backward produces them, so that
+        # data-parallel training can all-reduce finished ranges while backward continues (utils/dist.py)
+        order = [L for L in reversed(P.layers) if not L.frozen]
+        total = sum(L.dW.numel() + (2 * L.conv.out_channels if L.conv.norm is not None else L.conv.out_channels)
+                    for L in order)
+        P.arena = torch.zeros(total, device=dev)
+        off = 0
+        for L in order:
+            c = L.conv
+            L.dW = P.arena[off:off + L.dW.numel()].view(c.out_channels, c.kernel_size, c.kernel_size, c.in_channels)
+            off += L.dW.numel()
+            if c.norm is not None:
+                L.dgamma = P.arena[off:off + c.out_channels]
+                L.dbeta = P.arena[off + c.out_channels:off + 2 * c.out_channels]
+                off += 2 * c.out_channels
+            else:
+                L.dbias = P.arena[off:off + c.out_channels]
+                off += c.out_channels
+            L.arena_end = off
         n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
         P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
         n_wg = max(ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
@@ -325,6 +362,13 @@ class TrainEngine:
         for dv, g in zip(P.dheads, dheads):
             dv.interior()[..., :ak].copy_(g.permute(0, 2, 3, 1))
         head_grad = {id(dv.buf): g for dv, g in zip(P.dheads, dheads)}
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        if ddp:
+            if P.bucketer is None:
+                from .utils.dist import GradBucketer
+                P.bucketer = GradBucketer(P.arena, self.bucket_bytes, self.process_group)
+            P.bucketer.start()
         for L in reversed(P.layers):
             if L.frozen:
                 continue
@@ -337,6 +381,8 @@ class TrainEngine:
                 ops.bn_act_bwd(L.dy, L.z, L.stats, L.dz, L.dgamma, L.dbeta, P.bn_ws, slope=L.slope)
             dz = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, (c.out_channels + 7) // 8 * 8, 0)
             ops.conv2d_wgrad(L.x, dz, L.dW, P.wg_ws, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride)
+            if ddp:
+                P.bucketer.ready(L.arena_end)  # this layer's gradients are final: maybe launch a bucket
             if L.dx is None:
                 continue
             w, b = self._packed(L.name, "dgrad")
@@ -347,6 +393,8 @@ class TrainEngine:
                 src = L.dzd
             res = L.dx_add if L.dx_add is not None else (L.dx if L.dx_accumulate else None)
             ops.conv2d_fwd(src, w, b, L.dx, cin=cpad, cout=c.in_channels, k=c.kernel_size, stride=1, slope=1.0, residual=res)
+        if ddp:
+            P.bucketer.finish()
 
     def param_grads(self, P: TPlan) -> Dict[str, torch.Tensor]:
         """name -> gradient in the parameter's own layout ([Cout, Cin, k, k] views of the f32 buffers)."""
