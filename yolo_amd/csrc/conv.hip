@@ -53,14 +53,14 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 
 // T: element type of x / w / residual.  TC x TP: channel x pixel tile of one workgroup (4 waves laid
 // out WC x WP).  TAP2: bf16 with Cin == 32, one k-step spans two filter taps.
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
-    static_assert(WC * WP == 4, "4 waves");
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p) {
+    static_assert(WC * WP == NW, "waves");
     constexpr bool BF = sizeof(T) == 2;
     constexpr int W_BYTES = TC * ROWB, X_BYTES = TP * ROWB, BUF = W_BYTES + X_BYTES;
     constexpr int FC = TC / (16 * WC), FP = TP / (16 * WP);
-    constexpr int NWP = TC / 32, NXP = TP / 32;  // 1-KiB pieces per wave per operand
-    static_assert(TP * TC * 4 <= 2 * BUF, "epilogue staging must fit the operand buffers");
+    constexpr int NWP = TC / (8 * NW), NXP = TP / (8 * NW);  // 1-KiB pieces per wave per operand
+    static_assert(TC % (8 * NW) == 0 && TP % (8 * NW) == 0, "whole pieces per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -87,13 +87,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const char* xsrc[NXP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
-        const int row = 8 * (wave + 4 * i) + lrow;
+        const int row = 8 * (wave + NW * i) + lrow;
         wsrc[i] = p.w + (size_t)(tile_c * TC + row) * p.w_row_bytes + schunk * 16;
     }
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < NXP; ++i) {
-        const int row = 8 * (wave + 4 * i) + lrow;
+        const int row = 8 * (wave + NW * i) + lrow;
         int m = tile_p * TP + row;
         m = m < p.M ? m : p.M - 1;  // tail rows read a valid pixel; their results are never stored
         const int n = m / HoWo;
@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         }
         const int woff = cur_step * ROWB;
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + 4 * i) * 1024);
+        for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + NW * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < NXP; ++i) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + 4 * i) * 1024);
+        for (int i = 0; i < NXP; ++i) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + NW * i) * 1024);
         ++cur_step;
         if (++cur_cc == p.cpt) {
             cur_cc = 0;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
     // ---- epilogue 2: one lane = 8 channels of one pixel; whole pixel rows leave as contiguous bytes
     constexpr int G = TC / 8;       // 8-channel groups per pixel
-    constexpr int PPP = 256 / G;    // pixels per pass
+    constexpr int PPP = NW * 64 / G;  // pixels per pass
     const int g = tid % G;
     const int ch_first = tile_c * TC + g * 8;
     if (ch_first < p.Cout) {
@@ -281,17 +281,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2>
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * (TC + TP) * ROWB;
-    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2>;
+    // two operand buffers, or the f32 epilogue staging tile if that is larger
+    constexpr int LDS = 2 * (TC + TP) * ROWB > TP * TC * 4 ? 2 * (TC + TP) * ROWB : TP * TC * 4;
+    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int nblocks = p.n_ctiles * p.n_ptiles;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), LDS, stream, p);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }
