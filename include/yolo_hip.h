@@ -244,7 +244,7 @@ int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const float* stats,
  * Weight gradient of F.conv2d (bf16 or f32 operands per `dtype`, f32 result):
  *   dw[co][kh][kw][ci] (+)= sum_{n,ho,wo} dz[n][ho][wo][co] * x[n][ho*stride+kh-pad][wo*stride+kw-pad][ci]
  *   x   input view of the forward conv (halo >= pad);  dz  gradient view of its output (zero halo >= 1 unless
- *   N*Ho*Wo % 32 == 0);  accumulate != 0 adds to dw;  workspace: yolo_conv2d_wgrad_workspace_bytes(N*Ho*Wo, ...)
+ *   N*Ho*Wo % 64 == 0);  accumulate != 0 adds to dw;  workspace: yolo_conv2d_wgrad_workspace_bytes(N*Ho*Wo, ...)
  */
 int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N, int Cin, int Cout, int k, int stride,
                       int dtype, float* dw, int accumulate, void* workspace, size_t ws_bytes, void* stream);

@@ -60,6 +60,9 @@ def test_label_anchors_and_losses_match_oracle(model_cpu):
         assert torch.equal(a, b)
     for a, b in zip(mb, boxes):
         assert torch.equal(a, b)
+    bl, bb = model.label_anchors_batched(model.anchor_generator(feats_m), inst)   # what training_step uses
+    for a, b, c, d in zip(bl, labels, bb, boxes):
+        assert torch.equal(a, b) and torch.equal(c, d)
     for k in want:
         assert torch.allclose(got[k], want[k], rtol=1e-6, atol=1e-7), k
     sum(want.values()).backward()

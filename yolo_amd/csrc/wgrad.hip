@@ -6,7 +6,7 @@
 //
 // GEMM view per tap: D[co][ci] = sum_k A[co][k] * B[k][ci] with k = output pixel.  Both operands are stored
 // pixel-major (NHWC), i.e. k is the SLOW index of both, the opposite of what an MFMA operand register wants
-// (8 consecutive k per lane).  The tiles are therefore staged as they lie in memory -- [32 pixels][128
+// (8 consecutive k per lane).  The tiles are therefore staged as they lie in memory -- [64 pixels][128
 // channels] rows of 256 bytes, LDS-DMA, 16 bytes per lane -- and read with ds_read_b64_tr_b16, which hands
 // each lane one column (channel) of a 4-row (pixel) block: two such reads are one 16x16x32 operand.
 // 16-byte chunk c of row r sits at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3)) (source-side swizzle, same
@@ -51,8 +51,9 @@ __device__ __forceinline__ void divmod(int m, int d, float inv, int& q, int& r) 
 }
 
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 8 KiB + B 8 KiB)
-    constexpr int TILE = 32 * 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 16 KiB + B 16 KiB)
+    constexpr int KT = 64;            // pixels per k-step: two 16x16x32 MFMA slabs per barrier
+    constexpr int TILE = KT * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
@@ -72,15 +73,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     const int a_ch = mt * 128 + chunk * 8 < p.Cout ? mt * 128 + chunk * 8 : 0;
     const int b_ch = nt * 128 + chunk * 8 < p.Cin ? nt * 128 + chunk * 8 : 0;
     const long long x_tap = (long long)kh * p.x_row_stride + (long long)kw * p.x_pix_stride;
-    const int m_begin = split * p.steps_per_split * 32;
-    int m_end = m_begin + p.steps_per_split * 32;
+    const int m_begin = split * p.steps_per_split * KT;
+    int m_end = m_begin + p.steps_per_split * KT;
     if (m_end > p.M) m_end = p.M;
-    const int nsteps = (m_end - m_begin + 31) / 32;
+    const int nsteps = (m_end - m_begin + KT - 1) / KT;
 
     auto stage = [&](int step, char* buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m_begin + step * 32 + row0 + 16 * j;
+        for (int j = 0; j < KT / 16; ++j) {
+            const int m = m_begin + step * KT + row0 + 16 * j;
             const bool ok = m < m_end;
             int n, r, ho, wo;
             divmod(ok ? m : 0, p.HoWo, p.inv_HoWo, n, r);
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     // ---- consumer role: wave = 64 (co) x 64 (ci); transposed-read addresses (tile-independent)
     const int wm = wave >> 1, wn = wave & 1;
     const int q4 = l15 >> 2, p4 = l15 & 3;
-    int a_off[2][4], b_off[2][4];  // [half of the 8 k rows][fragment]
+    int a_off[2][4], b_off[2][4];  // [half of the 8 k rows][fragment], first 32-pixel slab; the second is + 32 rows
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int r = 8 * g + 4 * h + q4;
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto frag = [&](const char* buf, const int off[2][4], int f) {
+    auto frag = [&](const char* buf, const int off[2][4], int f) {   // swz(r + 32) == swz(r): slabs differ by a constant
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(buf + off[0][f]));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(buf + off[1][f]));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -133,15 +134,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         __syncthreads();
         if (s + 1 < nsteps) stage(s + 1, smem + ((s + 1) & 1) * 2 * TILE);
         const char* buf = smem + (s & 1) * 2 * TILE;
-        bf16x8 a[4], b[4];
+        bf16x8 a[2][4], b[2][4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) a[f] = frag(buf, a_off, f);
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) b[f] = frag(buf, b_off, f);
+            for (int f = 0; f < 4; ++f) a[kk][f] = frag(buf + kk * 32 * 256, a_off, f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int f = 0; f < 4; ++f) b[kk][f] = frag(buf + kk * 32 * 256, b_off, f);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
     }
 
     // ---- partial tile -> this split's slab
@@ -226,7 +233,7 @@ static void wgrad_plan(int M, int Cin, int Cout, int k, int* n_mt, int* n_nt, in
     *n_mt = (Cout + 127) / 128;
     *n_nt = (Cin + 127) / 128;
     const int tiles = *n_mt * *n_nt * k * k;
-    const int steps = (M + 31) / 32;
+    const int steps = (M + 63) / 64;
     int s = (1024 + tiles - 1) / tiles;  // ~2 rounds of 512 resident workgroups
     if (s > steps) s = steps;
     if (s < 1) s = 1;
@@ -305,7 +312,7 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "conv2d_wgrad: dtype %d", dtype);
     YOLO_REQUIRE(M < (1 << 24), "conv2d_wgrad: %lld output pixels (limit 2^24)", M);
     if (dtype == YOLO_F32) return wgrad_f32(x, dz, N, Cin, Cout, k, stride, dw, accumulate, workspace, ws_bytes, (hipStream_t)stream);
-    YOLO_REQUIRE(dz->halo >= 1 || M % 32 == 0, "conv2d_wgrad: dz needs a zero halo when N*Ho*Wo is not a multiple of 32");
+    YOLO_REQUIRE(dz->halo >= 1 || M % 64 == 0, "conv2d_wgrad: dz needs a zero halo when N*Ho*Wo is not a multiple of 64");
     // a tile row is 128 channels: reads past a narrower slice stay inside the buffer only with rows to spare
     YOLO_REQUIRE(dz->ch_total >= 128 || dz->halo >= 1, "conv2d_wgrad: dz narrower than 128 channels needs a halo");
     YOLO_REQUIRE(x->ch_total >= 128 || x->halo >= 1, "conv2d_wgrad: x narrower than 128 channels needs a halo");
@@ -339,7 +346,12 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
                  (size_t)p.splits * p.slab * sizeof(float));
     p.out = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int LDS = 2 * 2 * 32 * 256;
+    constexpr int LDS = 2 * 2 * 64 * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
     const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
     hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), LDS, st, p);
     long long rb = (p.slab + 255) / 256;

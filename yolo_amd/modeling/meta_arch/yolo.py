@@ -146,7 +146,7 @@ class YOLOV3(nn.Module):
             predictions, [self.num_classes, 1, 4])
         anchors = self.anchor_generator(features)
         grid_sizes = [f.shape[-2:] for f in features]
-        gt_labels, gt_boxes = self.label_anchors(anchors, gt_instances, grid_sizes)
+        gt_labels, gt_boxes = self.label_anchors_batched(anchors, gt_instances)
         return self.losses(anchors, pred_logits, pred_confs, pred_anchor_deltas, gt_labels, gt_boxes, self._get_strides())
 
     def losses(self, anchors: List[Boxes], pred_logits, pred_confs, pred_anchor_deltas, gt_labels, gt_boxes, strides):
@@ -182,6 +182,48 @@ class YOLOV3(nn.Module):
 
     def _compute_logits_loss(self, pred_logits, target):
         return F.binary_cross_entropy(pred_logits, target, reduction="mean")
+
+    @torch.no_grad()
+    def label_anchors_batched(self, anchors: List[Boxes], gt_instances: List[Instances]):
+        """label_anchors for the whole batch in a fixed number of tensor ops (the per-image loop of the reference,
+        yolo.py:223-262, costs ~30 tiny launches per image): ground truths are padded to the batch maximum and
+        masked.  Same rules as Matcher.__call__ (matcher.py:18-48); returns per-image lists like label_anchors."""
+        a = Boxes.cat(anchors).tensor                                   # [R, 4]
+        N, dev = len(gt_instances), a.device
+        K = max(max(len(g) for g in gt_instances), 1)
+        boxes = torch.zeros(N, K, 4, device=dev)
+        classes = torch.zeros(N, K, dtype=torch.int64, device=dev)
+        valid = torch.zeros(N, K, dtype=torch.bool, device=dev)
+        for n, g in enumerate(gt_instances):
+            k = len(g)
+            boxes[n, :k] = g.gt_boxes.tensor
+            classes[n, :k] = g.gt_classes
+            valid[n, :k] = True
+        area_g = (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])          # [N, K]
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])                                  # [R]
+        wh = (torch.min(boxes[:, :, None, 2:], a[None, None, :, 2:]) -
+              torch.max(boxes[:, :, None, :2], a[None, None, :, :2])).clamp_(min=0)
+        inter = wh[..., 0] * wh[..., 1]                                                     # [N, K, R]
+        mq = torch.where(inter > 0, inter / (area_g[..., None] + area_a - inter), inter.new_zeros(()))
+        best = mq.max(dim=2, keepdim=True).values
+        cg = (boxes[..., :2] + boxes[..., 2:]) / 2
+        ca = (a[:, :2] + a[:, 2:]) / 2
+        dist = (cg[:, :, None, :] - ca[None, None, :, :]).abs().sum(-1)
+        dist = torch.where(mq == best, dist, dist.new_full((), float("inf")))
+        pos = dist.argmin(dim=2)                                                            # [N, K] positive anchor per gt
+        mqv = torch.where(valid[..., None], mq, mq.new_full((), -1.0))
+        best_a, matches = mqv.max(dim=1)                                                    # [N, R]
+        labels = torch.full_like(matches, self.matcher_labels[1])
+        labels[best_a > self.matcher_threshold] = self.matcher_labels[0]
+        n_idx = torch.arange(N, device=dev)[:, None].expand(N, K)[valid]
+        k_idx = torch.arange(K, device=dev)[None, :].expand(N, K)[valid]
+        labels[n_idx, pos[valid]] = self.matcher_labels[2]
+        matches[n_idx, pos[valid]] = k_idx
+        gt_labels = classes.gather(1, matches)
+        gt_labels[labels == 0] = self.num_classes
+        gt_labels[labels == -1] = -1
+        gt_boxes = boxes.gather(1, matches[..., None].expand(-1, -1, 4))
+        return list(gt_labels.unbind(0)), list(gt_boxes.unbind(0))
 
     @torch.no_grad()
     def label_anchors(self, anchors: List[Boxes], gt_instances: List[Instances], grid_sizes):
