@@ -50,6 +50,9 @@ __device__ __forceinline__ void divmod(int m, int d, float inv, int& q, int& r) 
     }
 }
 
+// NARROW (Cin <= 64): the 4 waves split the 128 output channels four ways and each covers the 64 live input
+// channels, instead of 2 x 2 waves of 64 x 64 -- no matrix-core work on the dead half of the ci tile.
+template <bool NARROW>
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 16 KiB + B 16 KiB)
     constexpr int KT = 64;            // pixels per k-step: two 16x16x32 MFMA slabs per barrier
@@ -100,7 +103,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     };
 
     // ---- consumer role: wave = 64 (co) x 64 (ci); transposed-read addresses (tile-independent)
-    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int FM = NARROW ? 2 : 4;                 // 16-channel fragments of co per wave
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     const int q4 = l15 >> 2, p4 = l15 & 3;
     int a_off[2][4], b_off[2][4];  // [half of the 8 k rows][fragment], first 32-pixel slab; the second is + 32 rows
 #pragma unroll
@@ -108,15 +112,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         const int r = 8 * g + 4 * h + q4;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const int ca = wm * 8 + f * 2 + (p4 >> 1), cb = wn * 8 + f * 2 + (p4 >> 1);
+            const int ca = wm * 2 * FM + f * 2 + (p4 >> 1), cb = wn * 8 + f * 2 + (p4 >> 1);
             a_off[h][f] = 256 * r + 16 * (ca ^ swz(r)) + 8 * (p4 & 1);
             b_off[h][f] = TILE + 256 * r + 16 * (cb ^ swz(r)) + 8 * (p4 & 1);
         }
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[FM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -134,18 +138,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         __syncthreads();
         if (s + 1 < nsteps) stage(s + 1, smem + ((s + 1) & 1) * 2 * TILE);
         const char* buf = smem + (s & 1) * 2 * TILE;
-        bf16x8 a[2][4], b[2][4];
+        bf16x8 a[2][FM], b[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) a[kk][f] = frag(buf + kk * 32 * 256, a_off, f);
+            for (int f = 0; f < FM; ++f) a[kk][f] = frag(buf + kk * 32 * 256, a_off, f);
 #pragma unroll
             for (int f = 0; f < 4; ++f) b[kk][f] = frag(buf + kk * 32 * 256, b_off, f);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
@@ -154,13 +158,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     // ---- partial tile -> this split's slab
     float* out = p.out + (long long)split * p.slab;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ci = nt * 128 + wn * 64 + j * 16 + l15;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int co = mt * 128 + wm * 64 + i * 16 + 4 * g + e;
+                const int co = mt * 128 + wm * 16 * FM + i * 16 + 4 * g + e;
                 if (co < p.Cout && ci < p.Cin) out[((long long)co * p.taps + tap) * p.Cin + ci] = acc[i][j][e];
             }
         }
@@ -220,12 +224,26 @@ static void wgrad_f32_plan(int M, int Cin, int Cout, int k, int* splits, int* pi
     *splits = (M + *pix_per_split - 1) / *pix_per_split;
 }
 
+// dw[i] (+)= sum over splits of slabs[k][i].  Block = 32 consecutive elements x 8 split lanes (each lane strides
+// over the splits), folded through LDS: short dependent-load chains even for hundreds of splits.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slabs, float* dw, long long n, int splits,
                                                            int accumulate) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float s = accumulate ? dw[i] : 0.f;
-        for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
-        dw[i] = s;
+    __shared__ float part[8][33];
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (long long base = (long long)blockIdx.x * 32; base < n; base += (long long)gridDim.x * 32) {
+        const long long i = base + e;
+        float s = 0.f;
+        if (i < n)
+            for (int k = sl; k < splits; k += 8) s += slabs[(long long)k * n + i];
+        part[sl][e] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) {
+            float t = accumulate ? dw[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += part[k][e];
+            dw[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -234,8 +252,8 @@ static void wgrad_plan(int M, int Cin, int Cout, int k, int* n_mt, int* n_nt, in
     *n_nt = (Cin + 127) / 128;
     const int tiles = *n_mt * *n_nt * k * k;
     const int steps = (M + 63) / 64;
-    int s = (1024 + tiles - 1) / tiles;  // ~2 rounds of 512 resident workgroups
-    if (s > steps) s = steps;
+    int s = (1024 + tiles - 1) / tiles;  // ~2 rounds of 512 resident workgroups ...
+    if (s > steps / 8) s = steps / 8;     // ... but at least 8 k-steps per workgroup: a partial tile costs 64 KiB of slab
     if (s < 1) s = 1;
     *steps_per_split = (steps + s - 1) / s;
     *splits = (steps + *steps_per_split - 1) / *steps_per_split;
@@ -285,8 +303,8 @@ static int wgrad_f32(const yolo_view* x, const yolo_view* dz, int N, int Cin, in
     YOLO_REQUIRE(p.taps * p.splits <= 65535, "conv2d_wgrad f32: too many splits");
     p.out = (float*)workspace;
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3((Cin + 15) / 16, (Cout + 15) / 16, p.taps * p.splits), dim3(256), 0, st, p);
-    long long rb = (p.slab + 255) / 256;
-    if (rb > 4096) rb = 4096;
+    long long rb = (p.slab + 31) / 32;
+    if (rb > 8192) rb = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)workspace, dw, p.slab,
                        p.splits, accumulate);
     YOLO_CHECK_HIP(hipGetLastError());
@@ -349,13 +367,17 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     constexpr int LDS = 2 * 2 * 64 * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), LDS, st, p);
-    long long rb = (p.slab + 255) / 256;
-    if (rb > 4096) rb = 4096;
+    if (Cin <= 64)
+        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(blocks), dim3(256), LDS, st, p);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(blocks), dim3(256), LDS, st, p);
+    long long rb = (p.slab + 31) / 32;
+    if (rb > 8192) rb = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)workspace, dw, p.slab,
                        p.splits, accumulate);
     YOLO_CHECK_HIP(hipGetLastError());
