@@ -32,11 +32,19 @@ def _dist_setup(n_gpus: int):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # YOLO_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks then share cards); the measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("YOLO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local if world > 1 else 0)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     return world, rank, local
 
 
@@ -209,7 +217,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=model.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -72,25 +72,33 @@ def read_image_bgr(path: str) -> np.ndarray:
     return np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
 
 
-def setup(args):
-    cfg = get_cfg()
-    cfg.merge_from_file(args.config_file)
-    cfg.merge_from_list(args.opts)
-    cfg.MODEL.YOLOV3.TEST_SCORE_THRESH = args.score_confs  # the CLI defaults override the YAML, as in
-    cfg.MODEL.YOLOV3.TEST_NMS_THRESH = args.iou_thresh      # the reference (tools/inference.py:96-97)
-    cfg.freeze()
-    return cfg
+# the reference's flags (tools/inference.py:102-110), same names, defaults and meaning
+_FLAGS = (
+    ("--config-file", dict(metavar="FILE", default="configs/yolov3.yaml")),
+    ("--input", dict(nargs="+", required=True)),
+    ("--output", dict(default="./output")),
+    ("--score-confs", dict(type=float, default=0.5)),
+    ("--iou-thresh", dict(type=float, default=0.4)),
+    ("--opts", dict(default=None, nargs=argparse.REMAINDER)),
+)
 
 
 def get_parser():
-    parser = argparse.ArgumentParser(description="YOLO V3 Inference")
-    parser.add_argument("--config-file", metavar="FILE", default="configs/yolov3.yaml")
-    parser.add_argument("--input", nargs="+", required=True)
-    parser.add_argument("--output", default="./output")
-    parser.add_argument("--score-confs", type=float, default=0.5)
-    parser.add_argument("--iou-thresh", type=float, default=0.4)
-    parser.add_argument("--opts", default=None, nargs=argparse.REMAINDER)
-    return parser
+    ap = argparse.ArgumentParser(description="YOLO V3 Inference")
+    for flag, kw in _FLAGS:
+        ap.add_argument(flag, **kw)
+    return ap
+
+
+def setup(args):
+    """Config from the YAML, then --opts, then the two threshold flags, which always win over the YAML
+    (reference tools/inference.py:92-99)."""
+    cfg = get_cfg()
+    cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(list(args.opts or []) + ["MODEL.YOLOV3.TEST_SCORE_THRESH", str(args.score_confs),
+                                                 "MODEL.YOLOV3.TEST_NMS_THRESH", str(args.iou_thresh)])
+    cfg.freeze()
+    return cfg
 
 
 def main():
