@@ -15,6 +15,14 @@
 // Work split: one workgroup = one 128(co) x 128(ci) tile of one tap over one contiguous range of pixels
 // (split-K); partial tiles go to fp32 slabs, a second kernel adds the slabs.  Rows past the end of the pixel
 // range are fetched from a zero pixel of dz's halo, so they add nothing.
+//
+// Two ways to walk the pixels.  GATHER: k = output pixel (n, ho, wo), each tile row's address from two integer
+// divisions -- about 300 vector instructions per k-step against 32 MFMAs, which is what bounds that form.
+// LINEAR (stride 1, x and dz buffers of identical geometry, zero halo in dz): k = position in the halo'd
+// buffer, halo pixels included; dz is zero there, so they add nothing, x[k + tap offset] is always inside the
+// buffer, and every address is base + k * pixel stride.  Images are walked in segments of G consecutive
+// images (position range: first interior pixel of the first image .. last interior pixel of the last), G
+// chosen to minimise the number of 64-position k-steps.
 #include "common.h"
 
 namespace yolo {
@@ -33,6 +41,10 @@ struct WgradParams {
     int Cin, Cout, n_mt, n_nt, splits, steps_per_split;
     float* out;  // [splits][Cout][taps][Cin]
     long long slab;  // elements per split
+    // LINEAR mode: a segment = lin_len positions = lin_sps k-steps; byte offsets of a segment's first position
+    // (x_first: of tap (pad, pad)) and from one segment to the next
+    int lin_len, lin_sps, total_steps, pad;
+    long long dz_first, x_first, dz_seg_stride, x_seg_stride;
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -52,7 +64,7 @@ __device__ __forceinline__ void divmod(int m, int d, float inv, int& q, int& r) 
 
 // NARROW (Cin <= 64): the 4 waves split the 128 output channels four ways and each covers the 64 live input
 // channels, instead of 2 x 2 waves of 64 x 64 -- no matrix-core work on the dead half of the ci tile.
-template <bool NARROW>
+template <bool NARROW, bool LINEAR>
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 16 KiB + B 16 KiB)
     constexpr int KT = 64;            // pixels per k-step: two 16x16x32 MFMA slabs per barrier
@@ -79,9 +91,60 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     const int m_begin = split * p.steps_per_split * KT;
     int m_end = m_begin + p.steps_per_split * KT;
     if (m_end > p.M) m_end = p.M;
-    const int nsteps = (m_end - m_begin + KT - 1) / KT;
+    int nsteps = (m_end - m_begin + KT - 1) / KT;
+    // LINEAR: cursor (segment, k-step inside it) of the next stage() call; stage() is called for consecutive steps
+    int seg = 0, t = 0;
+    unsigned a_lane = 0, b_lane = 0;   // per-lane byte offsets (origin + tile row + channel chunk): below 2^32
+    long long tap_off = 0;             // wave-uniform
+    if constexpr (LINEAR) {
+        const int s_begin = split * p.steps_per_split;
+        int s_end = s_begin + p.steps_per_split;
+        if (s_end > p.total_steps) s_end = p.total_steps;
+        nsteps = s_end - s_begin;
+        seg = s_begin / p.lin_sps;
+        t = s_begin - seg * p.lin_sps;
+        a_lane = (unsigned)(p.dz_first + (long long)row0 * p.dz_pix_stride + a_ch * 2);
+        b_lane = (unsigned)(p.x_first + (long long)row0 * p.x_pix_stride + b_ch * 2);
+        tap_off = (long long)(kh - p.pad) * p.x_row_stride + (long long)(kw - p.pad) * p.x_pix_stride;
+    }
 
     auto stage = [&](int step, char* buf) {
+        if constexpr (LINEAR) {
+            const long long ua = (long long)seg * p.dz_seg_stride + (long long)t * (KT * p.dz_pix_stride);
+            const long long ub = (long long)seg * p.x_seg_stride + (long long)t * (KT * p.x_pix_stride);
+            if (t * KT + KT <= p.lin_len) {
+                // all 64 positions inside the segment (every k-step but a segment's last): wave-uniform base +
+                // the lane's loop-invariant 32-bit offset, no per-lane address arithmetic
+#pragma unroll
+                for (int j = 0; j < KT / 16; ++j) {
+                    const char* a = p.dz + (ua + 16 * j * p.dz_pix_stride) + a_lane;
+                    const char* b = p.x + (ub + tap_off + 16 * j * p.x_pix_stride) + b_lane;
+                    char* la = buf + (16 * j + 4 * wave) * 256;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                                     (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b,
+                                                     (__attribute__((address_space(3))) void*)(la + TILE), 16, 0, 0);
+                }
+            } else {
+                const int idx0 = t * KT + row0;
+#pragma unroll
+                for (int j = 0; j < KT / 16; ++j) {
+                    const bool ok = idx0 + 16 * j < p.lin_len;
+                    const char* a = ok ? p.dz + (ua + 16 * j * p.dz_pix_stride) + a_lane : p.dz + p.dz_zero + (a_ch & 127) * 2;
+                    const char* b = ok ? p.x + (ub + tap_off + 16 * j * p.x_pix_stride) + b_lane : p.x + p.x_first + b_ch * 2;
+                    char* la = buf + (16 * j + 4 * wave) * 256;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                                     (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b,
+                                                     (__attribute__((address_space(3))) void*)(la + TILE), 16, 0, 0);
+                }
+            }
+            if (++t == p.lin_sps) {
+                t = 0;
+                ++seg;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < KT / 16; ++j) {
             const int m = m_begin + step * KT + row0 + 16 * j;
@@ -247,16 +310,76 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slabs, f
     }
 }
 
-static void wgrad_plan(int M, int Cin, int Cout, int k, int* n_mt, int* n_nt, int* splits, int* steps_per_split) {
+// The same sum for large gradients (n % 4 == 0): one thread per 4 consecutive elements, 16-byte loads, the splits
+// in order, four loads in flight.
+__global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const f32x4* slabs, f32x4* dw, long long n4, int splits,
+                                                            int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 t = accumulate ? dw[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+        const f32x4 a = slabs[(long long)k * n4 + i], b = slabs[(long long)(k + 1) * n4 + i];
+        const f32x4 c = slabs[(long long)(k + 2) * n4 + i], d = slabs[(long long)(k + 3) * n4 + i];
+        t += a;
+        t += b;
+        t += c;
+        t += d;
+    }
+    for (; k < splits; ++k) t += slabs[(long long)k * n4 + i];
+    dw[i] = t;
+}
+
+static void launch_wgrad_reduce(const void* ws, float* dw, long long n, int splits, int accumulate, hipStream_t st) {
+    // enough 16-byte threads to fill the chip (and few enough splits to walk in one thread): the wide form
+    if (n % 4 == 0 && n / 4 >= 64 * 1024 && splits <= 64) {
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const f32x4*)ws,
+                           (f32x4*)dw, n / 4, splits, accumulate);
+        return;
+    }
+    long long rb = (n + 31) / 32;
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)ws, dw, n, splits, accumulate);
+}
+
+static int wgrad_target_blocks(int k) {
+    static const int v1 = getenv("YOLO_WGRAD_BLOCKS1") ? atoi(getenv("YOLO_WGRAD_BLOCKS1")) : 512;
+    static const int v3 = getenv("YOLO_WGRAD_BLOCKS3") ? atoi(getenv("YOLO_WGRAD_BLOCKS3")) : 1024;
+    return k == 1 ? v1 : v3;
+}
+
+// `steps` k-steps of 64 pixels (or positions); at most `max_splits` slabs fit the workspace.  512 workgroups are
+// resident at a time (two per CU): the split count is the largest that keeps the grid within a whole number of
+// such rounds (one for the memory-bound 1x1 layers, whose slabs cost as much as their operands; two for 3x3) --
+// a few workgroups more than that would run as a round of their own.
+static void wgrad_plan(int steps, int Cin, int Cout, int k, long long max_splits, int* n_mt, int* n_nt, int* splits,
+                       int* steps_per_split) {
     *n_mt = (Cout + 127) / 128;
     *n_nt = (Cin + 127) / 128;
     const int tiles = *n_mt * *n_nt * k * k;
-    const int steps = (M + 63) / 64;
-    int s = (1024 + tiles - 1) / tiles;  // ~2 rounds of 512 resident workgroups ...
-    if (s > steps / 8) s = steps / 8;     // ... but at least 8 k-steps per workgroup: a partial tile costs 64 KiB of slab
+    long long s = wgrad_target_blocks(k) / tiles;
+    if (s > steps / 8) s = steps / 8;     // at least 8 k-steps per workgroup: a partial tile costs 64 KiB of slab
+    if (s > max_splits) s = max_splits;
     if (s < 1) s = 1;
-    *steps_per_split = (steps + s - 1) / s;
+    *steps_per_split = (int)((steps + s - 1) / s);
     *splits = (steps + *steps_per_split - 1) / *steps_per_split;
+}
+
+// LINEAR walk: images per segment G (a divisor of N) with the fewest k-steps; positions and steps per segment
+static void wgrad_linear_plan(int N, int H, int W, int halo, int* G, int* len, int* sps) {
+    const long long Hp = H + 2 * halo, Wp = W + 2 * halo;
+    long long best = -1;
+    for (int g = 1; g <= N; ++g) {
+        if (N % g) continue;
+        const long long l = (long long)(g - 1) * Hp * Wp + (long long)(H - 1) * Wp + W;
+        const long long st = (l + 63) / 64, total = st * (N / g);
+        if (l < (1 << 30) && (best < 0 || total < best)) {
+            best = total;
+            *G = g;
+            *len = (int)l;
+            *sps = (int)st;
+        }
+    }
 }
 
 }  // namespace yolo
@@ -265,8 +388,10 @@ using namespace yolo;
 
 extern "C" size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k) {
     if (M <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
+    // the halo'd-buffer walk takes more k-steps than there are pixels (how many depends on the image size, which
+    // this query does not see): sized for twice the steps; a launch never uses more slabs than fit what it is given
     int n_mt, n_nt, splits, sps, s32, pps;
-    wgrad_plan(M, Cin, Cout, k, &n_mt, &n_nt, &splits, &sps);
+    wgrad_plan(2 * ((M + 63) / 64), Cin, Cout, k, 1 << 20, &n_mt, &n_nt, &splits, &sps);
     wgrad_f32_plan(M, Cin, Cout, k, &s32, &pps);
     if (s32 > splits) splits = s32;
     return (size_t)splits * Cout * k * k * Cin * sizeof(float);
@@ -303,10 +428,7 @@ static int wgrad_f32(const yolo_view* x, const yolo_view* dz, int N, int Cin, in
     YOLO_REQUIRE(p.taps * p.splits <= 65535, "conv2d_wgrad f32: too many splits");
     p.out = (float*)workspace;
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3((Cin + 15) / 16, (Cout + 15) / 16, p.taps * p.splits), dim3(256), 0, st, p);
-    long long rb = (p.slab + 31) / 32;
-    if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)workspace, dw, p.slab,
-                       p.splits, accumulate);
+    launch_wgrad_reduce(workspace, dw, p.slab, p.splits, accumulate, st);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }
@@ -358,28 +480,41 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     p.inv_Wo = 1.0f / (float)Wo;
     p.Cin = Cin;
     p.Cout = Cout;
-    wgrad_plan((int)M, Cin, Cout, k, &p.n_mt, &p.n_nt, &p.splits, &p.steps_per_split);
     p.slab = (long long)Cout * k * k * Cin;
-    YOLO_REQUIRE(ws_bytes >= (size_t)p.splits * p.slab * sizeof(float), "conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes,
-                 (size_t)p.splits * p.slab * sizeof(float));
+    const long long max_splits = (long long)(ws_bytes / ((size_t)p.slab * sizeof(float)));
+    YOLO_REQUIRE(max_splits >= 1, "conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, (size_t)p.slab * sizeof(float));
+    // same geometry on both sides and a (zero) halo in dz: walk the halo'd buffers linearly
+    static const bool allow_linear = !(getenv("YOLO_WGRAD_GATHER") && atoi(getenv("YOLO_WGRAD_GATHER")));
+    const bool linear = allow_linear && stride == 1 && x->halo == dz->halo && dz->halo >= 1 && x->H == dz->H && x->W == dz->W;
+    int steps = ((int)M + 63) / 64;
+    if (linear) {
+        int G = 1;
+        wgrad_linear_plan(N, Ho, Wo, dz->halo, &G, &p.lin_len, &p.lin_sps);
+        p.total_steps = p.lin_sps * (N / G);
+        p.pad = pad;
+        p.dz_first = (long long)gd.origin * 2;
+        p.x_first = (long long)gx.origin * 2;
+        p.dz_seg_stride = (long long)G * p.dz_img_stride;
+        p.x_seg_stride = (long long)G * p.x_img_stride;
+        steps = p.total_steps;
+    }
+    wgrad_plan(steps, Cin, Cout, k, max_splits, &p.n_mt, &p.n_nt, &p.splits, &p.steps_per_split);
     p.out = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     constexpr int LDS = 2 * 2 * 64 * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
-    if (Cin <= 64)
-        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(blocks), dim3(256), LDS, st, p);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(blocks), dim3(256), LDS, st, p);
-    long long rb = (p.slab + 31) / 32;
-    if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)workspace, dw, p.slab,
-                       p.splits, accumulate);
+    auto kern = Cin <= 64 ? (linear ? wgrad_kernel<true, true> : wgrad_kernel<true, false>)
+                          : (linear ? wgrad_kernel<false, true> : wgrad_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
+    launch_wgrad_reduce(workspace, dw, p.slab, p.splits, accumulate, st);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }
