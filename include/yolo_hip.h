@@ -261,6 +261,23 @@ size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k);
 int yolo_pack_conv_train(const float* w, int Cout, int Cin, int k, int dtype, void* w_fwd, int fwd_row,
                          void* w_dgrad, int dgrad_row, int Cout_pad, void* stream);
 
+/*
+ * yolo_pack_conv_train for every trainable convolution of a model in one launch, for master weights stored
+ * pixel-major: w [Cout][k][k][Cin] fp32 (the storage of a torch channels_last [Cout,Cin,k,k] tensor, which is
+ * also the layout yolo_conv2d_wgrad writes, so parameters, gradients and optimizer state share one layout).
+ *   descs_device  table of n_layers entries in DEVICE memory; first_tile = running sum of
+ *                 ceil(Cout/64) * k*k * ceil(Cin/64) over the preceding entries; total_tiles = the full sum
+ *   w_fwd / w_dgrad, fwd_row, dgrad_row, Cout_pad: as for yolo_pack_conv_train (w_dgrad may be NULL)
+ */
+typedef struct yolo_pack_desc {
+    const void* w;
+    void* w_fwd;
+    void* w_dgrad;
+    int Cout, Cin, k, fwd_row, dgrad_row, Cout_pad, first_tile, reserved;
+} yolo_pack_desc;
+int yolo_pack_conv_train_batch(const yolo_pack_desc* descs_device, int n_layers, int total_tiles, int dtype,
+                               void* stream);
+
 /* y[2i][2j] = x[i][j], zeros elsewhere in each 2x2 cell (input of a stride-2 conv's data gradient). */
 int yolo_dilate2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
 /* y[i][j] = sum of the 2x2 cell of x: backward of nn.Upsample(2, "nearest") (fpn.py:31,36). */

@@ -185,3 +185,48 @@ def test_sgd_steps_reduce_the_loss(cuda):
     assert all(torch.isfinite(torch.tensor(hist)))
     assert hist[-1] < hist[0], hist
     model.eval()
+
+
+def test_param_grads_alias_the_arena_and_still_accumulate(cuda):
+    """The trainable parameters live in the engine's flat arena (channels_last conv weights) and ``.grad`` is a
+    slice of the gradient arena; backward() twice without zero_grad() accumulates, a gradient tensor assigned by
+    the caller is added to by autograd, and the state dict still has the reference's names, shapes and values."""
+    model, cfg, sd, imgs, gb, gc, inputs = _make("f32", N=2, S=64)
+    model.train()
+    sum(model(inputs).values()).backward()
+    eng = model.backbone.train_engine()
+    views = eng.grad_views()
+    assert len(views) == 210
+    lo, hi = eng.grad_arena.data_ptr(), eng.grad_arena.data_ptr() + eng.grad_arena.numel() * 4
+    for p, g in views:
+        assert p.grad is not None and p.grad.data_ptr() == g.data_ptr() and lo <= g.data_ptr() < hi
+        assert p.grad.shape == p.shape and p.grad.stride() == p.stride()
+        assert eng.param_arena.data_ptr() <= p.data_ptr() < eng.param_arena.data_ptr() + eng.param_arena.numel() * 4
+    w = model.backbone.bottom_up.res3[0].conv2.weight
+    assert w.shape == (256, 128, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+    for k, v in model.state_dict().items():   # adoption moved storage, not values
+        if "running" not in k and "num_batches" not in k:
+            assert v.shape == sd[k].shape and torch.equal(v.cpu(), sd[k]), k
+    once = {id(p): p.grad.clone() for p, _ in views}
+    # BatchNorm running statistics moved, the parameters did not: the second backward gives the same gradient
+    sum(model(inputs).values()).backward()
+    for p, _ in views[:40]:
+        assert _l2(p.grad, 2 * once[id(p)]) < 1e-5
+    # a gradient tensor of the caller's own: autograd adds to it, the arena slice is not installed
+    for p, _ in views:
+        p.grad = None
+    p0, g0 = views[3]
+    mine = torch.ones_like(p0)
+    p0.grad = mine
+    sum(model(inputs).values()).backward()
+    assert p0.grad.data_ptr() == mine.data_ptr() and _l2(p0.grad - 1, once[id(p0)]) < 1e-5
+    assert views[4][0].grad.data_ptr() == views[4][1].data_ptr()
+    # storage replaced from outside is re-adopted on the next step
+    with torch.no_grad():
+        w.data = (w.data * 1.0).contiguous()
+    for p, _ in views:
+        p.grad = None
+    sum(model(inputs).values()).backward()
+    assert eng.param_arena.data_ptr() <= w.data_ptr() < eng.param_arena.data_ptr() + eng.param_arena.numel() * 4
+    assert _l2(w.grad, once[id(w)]) < 1e-5
+    model.eval()

@@ -155,3 +155,33 @@ def test_dilate_and_sum2x2(cuda):
     torch.cuda.synchronize()
     ref = F.avg_pool2d(up, 2) * 4
     assert _rel(sv.nchw().float().cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pack_conv_train_batch(cuda, dtype):
+    """One launch packs every layer: channels_last master weights -> the forward and data-gradient operand layouts
+    that the torch-side packers (ops.pack_conv / ops.pack_conv_dgrad) produce."""
+    from yolo_amd import ops
+    torch.manual_seed(5)
+    shapes = [(128, 64, 3), (64, 128, 1), (255, 256, 1), (256, 128, 3), (75, 512, 1)]
+    entries, keep = [], []
+    for cout, cin, k in shapes:
+        w = torch.randn(cout, cin, k, k, device=cuda).contiguous(memory_format=torch.channels_last)
+        if k == 1:  # channels_last is ambiguous for 1x1: build the storage explicitly
+            w = torch.randn(cout, k, k, cin, device=cuda).permute(0, 3, 1, 2)
+        cpad = (cout + 63) // 64 * 64
+        fwd = torch.zeros(ops.lib().yolo_conv_cout_pad(cout), k * k * cin, dtype=dtype, device=cuda)
+        dg = torch.zeros(ops.lib().yolo_conv_cout_pad(cin), k * k * cpad, dtype=dtype, device=cuda)
+        entries.append((w, fwd, dg, cpad))
+        keep.append((w, fwd, dg, cpad))
+    tbl = ops.pack_table(entries, cuda)
+    ops.pack_conv_train_batch(*tbl, dtype)
+    torch.cuda.synchronize()
+    for (cout, cin, k), (w, fwd, dg, cpad) in zip(shapes, keep):
+        want_f, _ = ops.pack_conv(w.contiguous(), torch.zeros(cout), dtype, cuda)
+        assert torch.equal(fwd[:cout].float().cpu(), want_f[:cout, :k * k * cin].float().cpu()), (cout, cin, k)
+        assert float(fwd[cout:].abs().max()) == 0.0 if fwd.shape[0] > cout else True
+        wpad = torch.zeros(cpad, cin, k, k, device=cuda)
+        wpad[:cout] = w
+        want_d, _ = ops.pack_conv_dgrad(wpad, dtype, cuda)
+        assert torch.equal(dg[:cin].float().cpu(), want_d[:cin, :k * k * cpad].float().cpu()), (cout, cin, k)

@@ -599,3 +599,68 @@ extern "C" int yolo_pack_conv_train(const float* w, int Cout, int Cin, int k, in
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }
+
+namespace yolo {
+
+// All trainable convolutions of a model in ONE launch.  Master weights live pixel-major, [Cout][kh][kw][Cin] fp32
+// (the storage order of a torch channels_last [Cout,Cin,kh,kw] tensor), so the forward operand is a cast copy;
+// the data-gradient operand [ci][rotated tap][co] goes through a 64 x 64 LDS transpose.  One workgroup = one
+// (64 co, tap, 64 ci) tile; the layer of a workgroup is found by bisection over the table's first-tile column.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_train_batch_kernel(const yolo_pack_desc* descs, int n_layers) {
+    __shared__ T tile[64][66];
+    int lo = 0, hi = n_layers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= descs[mid].first_tile) lo = mid; else hi = mid - 1;
+    }
+    const yolo_pack_desc d = descs[lo];
+    const int kk = d.k * d.k;
+    int id = blockIdx.x - d.first_tile;
+    const int n_ci = (d.Cin + 63) / 64;
+    const int ct = id % n_ci;
+    id /= n_ci;
+    const int t = id % kk;
+    const int cot = id / kk;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* w = (const float*)d.w;
+    T* fwd = (T*)d.w_fwd;
+    T* dg = (T*)d.w_dgrad;
+    const int ci = ct * 64 + tx;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int co = cot * 64 + r;
+        T o = 0;
+        if (co < d.Cout && ci < d.Cin) {
+            const float v = w[((long long)co * kk + t) * d.Cin + ci];
+            if constexpr (sizeof(T) == 2) o = f32_to_bf16_bits(v); else o = v;
+            if (fwd) fwd[(long long)co * d.fwd_row + t * d.Cin + ci] = o;
+        }
+        tile[r][tx] = o;
+    }
+    if (!dg) return;
+    __syncthreads();
+    const int co = cot * 64 + tx;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int c = ct * 64 + r;
+        if (c < d.Cin && co < d.Cout) dg[(long long)c * d.dgrad_row + (kk - 1 - t) * d.Cout_pad + co] = tile[tx][r];
+    }
+}
+
+}  // namespace yolo
+
+extern "C" int yolo_pack_conv_train_batch(const yolo_pack_desc* descs_device, int n_layers, int total_tiles, int dtype,
+                                          void* stream) {
+    YOLO_REQUIRE(descs_device && n_layers > 0 && total_tiles > 0, "pack_conv_train_batch: empty table");
+    YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "pack_conv_train_batch: dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((yolo::pack_train_batch_kernel<unsigned short>), dim3((unsigned)total_tiles), dim3(256), 0, st,
+                           descs_device, n_layers);
+    else
+        hipLaunchKernelGGL((yolo::pack_train_batch_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, st,
+                           descs_device, n_layers);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}

@@ -149,7 +149,7 @@ class DarkNetFPN(Backbone):
         gradients in the parameters' ``.grad``."""
         eng = self.train_engine()
         named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
-        outs = _TrainFunction.apply(eng, images, tuple(mean), tuple(std), [n for n, _ in named], *[p for _, p in named])
+        outs = _TrainFunction.apply(eng, images, tuple(mean), tuple(std), named, *[p for _, p in named])
         return dict(zip(self._out_features, outs))
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -183,19 +183,41 @@ class _TrainFunction(torch.autograd.Function):
     coming out."""
 
     @staticmethod
-    def forward(ctx, eng, images, mean, std, names, *params):
+    def forward(ctx, eng, images, mean, std, named, *params):
         heads = eng.forward(images, mean, std)
         N, _, Hs, Ws = images.shape
-        ctx.eng, ctx.names = eng, names
+        ctx.eng, ctx.named = eng, named
         ctx.plan = eng.plan(N, (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         return tuple(h.nchw() for h in heads)
 
     @staticmethod
     def backward(ctx, *dheads):
+        """Runs the backward plan, which leaves every parameter gradient in the engine's gradient arena, laid out
+        like the parameters.  A parameter without a gradient gets its arena slice AS its ``.grad`` (no copy; the
+        usual zero_grad() -> backward() -> step() loop always takes this route).  A ``.grad`` that already is the
+        arena slice keeps accumulation semantics: what it held is added back.  Any other ``.grad`` tensor is left
+        to autograd, which adds the returned gradient to it."""
+        eng = ctx.eng
         dheads = [d if d is not None else torch.zeros_like(h.nchw()) for d, h in zip(dheads, ctx.plan.heads)]
-        ctx.eng.backward(ctx.plan, dheads)
-        g = ctx.eng.param_grads(ctx.plan)
-        return (None, None, None, None, None) + tuple(g.get(n) for n in ctx.names)
+        views = {id(p): g for p, g in eng.grad_views()}
+        held = [(p, p.grad.clone()) for _, p in ctx.named
+                if p.grad is not None and id(p) in views and p.grad.data_ptr() == views[id(p)].data_ptr()]
+        eng.backward(ctx.plan, dheads)
+        out = []
+        for _, p in ctx.named:
+            g = views.get(id(p))
+            if g is None:
+                out.append(None)
+            elif p.grad is None:
+                p.grad = g
+                out.append(None)
+            elif p.grad.data_ptr() == g.data_ptr():
+                out.append(None)
+            else:
+                out.append(g)
+        for p, old in held:
+            p.grad.add_(old)
+        return (None, None, None, None, None) + tuple(out)
 
 
 @BACKBONE_REGISTRY.register()

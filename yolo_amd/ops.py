@@ -422,3 +422,38 @@ def pack_conv_train(weight: torch.Tensor, w_fwd: Optional[torch.Tensor], w_dgrad
                                      0 if w_fwd is None else w_fwd.shape[1], _ptr(w_dgrad),
                                      0 if w_dgrad is None else w_dgrad.shape[1], cout_pad, _stream()),
           "yolo_pack_conv_train")
+
+
+class PackDesc(ctypes.Structure):
+    """yolo_pack_desc of include/yolo_hip.h."""
+    _fields_ = [("w", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
+                ("Cout", ctypes.c_int), ("Cin", ctypes.c_int), ("k", ctypes.c_int), ("fwd_row", ctypes.c_int),
+                ("dgrad_row", ctypes.c_int), ("Cout_pad", ctypes.c_int), ("first_tile", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+def pack_table(entries, device):
+    """entries: (weight [Cout,Cin,k,k] f32 stored channels_last, w_fwd 2-D, w_dgrad 2-D or None, cout_pad) per layer.
+    Returns (device table, number of layers, total tiles) for pack_conv_train_batch; the tensors must stay alive
+    and in place for as long as the table is used."""
+    arr = (PackDesc * len(entries))()
+    tiles = 0
+    for d, (w, w_fwd, w_dgrad, cout_pad) in zip(arr, entries):
+        cout, cin, k, _ = w.shape
+        assert w.dtype == torch.float32 and w.permute(0, 2, 3, 1).is_contiguous(), "master weights must be channels_last"
+        d.w, d.w_fwd, d.w_dgrad = w.data_ptr(), w_fwd.data_ptr(), (0 if w_dgrad is None else w_dgrad.data_ptr())
+        d.Cout, d.Cin, d.k, d.fwd_row = cout, cin, k, w_fwd.shape[1]
+        d.dgrad_row, d.Cout_pad = (0 if w_dgrad is None else w_dgrad.shape[1]), cout_pad
+        assert d.fwd_row >= k * k * cin and (w_dgrad is None or d.dgrad_row >= k * k * cout_pad)
+        d.first_tile = tiles
+        tiles += ((cout + 63) // 64) * k * k * ((cin + 63) // 64)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return raw, len(entries), tiles
+
+
+def pack_conv_train_batch(table: torch.Tensor, n_layers: int, total_tiles: int, dtype: torch.dtype) -> None:
+    """One launch for every trainable convolution: channels_last f32 master weights -> forward and data-gradient
+    operand buffers (see pack_table)."""
+    _require_cuda(table, "pack_conv_train_batch")
+    check(lib().yolo_pack_conv_train_batch(_ptr(table), n_layers, total_tiles, dtype_code(dtype), _stream()),
+          "yolo_pack_conv_train_batch")

@@ -17,6 +17,13 @@ fused inference kernels and take no part in the backward pass.  Activations are 
 every activation that backward needs has its own buffer (nothing is recomputed); weight, gamma and beta
 gradients are fp32.  nn.Upsample + torch.cat stay free in forward (channel slices of one buffer); their
 backward is a channel slice of the gradient buffer plus one 2x2-sum kernel.
+
+Parameters and their gradients live in two flat fp32 arenas with one layout, in the order backward produces the
+gradients: conv weights pixel-major [Cout][kh][kw][Cin] (to torch: channels_last tensors of the usual
+[Cout,Cin,kh,kw] shape), then gamma and beta (or the head's bias).  The trainable nn.Parameters are re-pointed at
+views of the parameter arena the first time a plan is built ("adopted"); the weight-gradient kernel writes its
+result in that same layout, so ``param.grad`` can alias the gradient arena -- no per-parameter copies, the
+optimizer's multi-tensor kernels see matching strides, and data-parallel training all-reduces arena ranges.
 """
 from __future__ import annotations
 
@@ -106,6 +113,13 @@ class TrainEngine:
         self._zero_bias: Dict[int, torch.Tensor] = {}
         self.bucket_bytes = 64 << 20
         self.process_group = None
+        self.param_arena: Optional[torch.Tensor] = None
+        self.grad_arena: Optional[torch.Tensor] = None
+        self._adopted: List[Tuple[torch.nn.Parameter, torch.Tensor, torch.Tensor]] = []  # (param, data view, grad view)
+        self._slots: Dict[str, Tuple[int, int]] = {}     # layer name -> (offset of dW in the arenas, arena end)
+        self._order: List[str] = []                       # trainable layers in backward order
+        self._pack_tbl = None
+        self._pack_ver = None
 
     # ------------------------------------------------------------------ packing (weights change every step)
     def _zeros(self, n: int) -> torch.Tensor:
@@ -113,7 +127,86 @@ class TrainEngine:
             self._zero_bias[n] = torch.zeros(n, device=self.device)
         return self._zero_bias[n]
 
+    def _train_bufs(self, name: str):
+        """Operand buffers of a trainable conv, allocated and zero-padded once: (forward weights, data-gradient
+        weights, forward bias, zero bias of the data-gradient conv).  "raw" = the bare convolution (+ bias for the
+        heads); "dgrad" = Cin <-> Cout with the taps rotated, Cout padded to what the kernel reads."""
+        bufs = self._wbufs.get(name)
+        if bufs is None:
+            conv = self.convs[name]
+            k, cin, cout = conv.kernel_size, conv.in_channels, conv.out_channels
+            cpad = (cout + 63) // 64 * 64
+            mk = lambda rows, cols: torch.zeros(rows, cols, dtype=self.dtype, device=self.device)  # noqa: E731
+            extra = 32 if (self.dtype == torch.bfloat16 and k == 3) else 0   # a 32-channel row spans two taps
+            bufs = (mk(ops.lib().yolo_conv_cout_pad(cout), k * k * cin + (extra if cin == 32 else 0)),
+                    mk(ops.lib().yolo_conv_cout_pad(cin), k * k * cpad + (extra if cpad == 32 else 0)),
+                    torch.zeros(ops.lib().yolo_conv_cout_pad(cout), device=self.device),
+                    torch.zeros(ops.lib().yolo_conv_cout_pad(cin), device=self.device))
+            self._wbufs[name] = bufs
+        return bufs
+
+    def _pack_all(self) -> None:
+        """Repack every trainable conv's master weights into its operand buffers -- one launch, and only when an
+        optimizer step (or a checkpoint load) has touched them since the last time."""
+        self._check_adopted()
+        convs = [self.convs[n] for n in self._order]
+        ver = tuple((c.weight._version, None if c.bias is None else c.bias._version) for c in convs)
+        if ver == self._pack_ver:
+            return
+        if self._pack_tbl is None:
+            entries = []
+            for n, c in zip(self._order, convs):
+                b = self._train_bufs(n)
+                entries.append((c.weight.data, b[0], b[1], (c.out_channels + 63) // 64 * 64))
+            self._pack_tbl = ops.pack_table(entries, self.device)
+        ops.pack_conv_train_batch(*self._pack_tbl, self.dtype)
+        for n, c in zip(self._order, convs):
+            if c.bias is not None:
+                self._wbufs[n][2][:c.out_channels].copy_(c.bias.detach())
+        self._pack_ver = ver
+
+    # ------------------------------------------------------------------ flat parameter / gradient arenas
+    def _adopt(self, order: "List[TLayer]") -> None:
+        """Lay out the arenas for the trainable layers (in backward order) and re-point the parameters at them."""
+        total = sum(L.conv.weight.numel() + (2 if L.conv.norm is not None else 1) * L.conv.out_channels for L in order)
+        self.param_arena = torch.empty(total, device=self.device)
+        self.grad_arena = torch.zeros(total, device=self.device)
+        off = 0
+        for L in order:
+            c = L.conv
+            co, ci, k = c.out_channels, c.in_channels, c.kernel_size
+            start = off
+            parts = [(c.weight, c.weight.numel(), lambda a: a.view(co, k, k, ci).permute(0, 3, 1, 2))]
+            flat = lambda a: a  # noqa: E731
+            if c.norm is not None:
+                parts += [(c.norm.weight, co, flat), (c.norm.bias, co, flat)]
+            else:
+                parts += [(c.bias, co, flat)]
+            for prm, n, shape in parts:
+                self._adopted.append((prm, shape(self.param_arena[off:off + n]), shape(self.grad_arena[off:off + n])))
+                off += n
+            self._slots[L.name] = (start, off)
+            self._order.append(L.name)
+        self._check_adopted()
+
+    def _check_adopted(self) -> None:
+        """A parameter whose storage was replaced from outside (module.to(), an assigned state dict) is copied
+        back into the arena and re-pointed; in-place updates (optimizer steps, load_state_dict) never trigger this."""
+        for prm, view, _ in self._adopted:
+            if prm.data_ptr() != view.data_ptr() or prm.stride() != view.stride():
+                with torch.no_grad():
+                    view.copy_(prm.data)
+                prm.data = view
+                self._pack_ver = None
+
+    def grad_views(self) -> "List[Tuple[torch.nn.Parameter, torch.Tensor]]":
+        """(parameter, its slice of the gradient arena shaped and strided like the parameter)."""
+        return [(prm, g) for prm, _, g in self._adopted]
+
     def _packed(self, name: str, kind: str):
+        if kind in ("raw", "dgrad") and name not in self.frozen:
+            b = self._train_bufs(name)
+            return (b[0], b[2]) if kind == "raw" else (b[1], b[3])
         conv = self.convs[name]
         ver = (conv.weight._version, None if conv.bias is None else conv.bias._version,
                None if conv.norm is None else tuple(t._version for t in conv.norm.as_dict().values()))
@@ -126,26 +219,7 @@ class TrainEngine:
             pw, pb = (ops.pack_stem(w, b, self.device) if conv.in_channels == 3
                       else ops.pack_conv(w, b, self.dtype, self.device))
         else:
-            # trainable layer: "raw" = the bare convolution (+ bias for the heads); "dgrad" = Cin <-> Cout with the
-            # taps rotated, Cout padded to what the kernel reads.  Both come from ONE repacking launch per step
-            # into buffers allocated (and zero-padded) once.
-            k, cin, cout = conv.kernel_size, conv.in_channels, conv.out_channels
-            cpad = (cout + 63) // 64 * 64
-            bufs = self._wbufs.get(name)
-            if bufs is None:
-                mk = lambda rows, cols: torch.zeros(rows, cols, dtype=self.dtype, device=self.device)  # noqa: E731
-                extra = 32 if (self.dtype == torch.bfloat16 and k == 3) else 0   # a 32-channel row spans two taps
-                bufs = (mk(ops.lib().yolo_conv_cout_pad(cout), k * k * cin + (extra if cin == 32 else 0)),
-                        mk(ops.lib().yolo_conv_cout_pad(cin), k * k * cpad + (extra if cpad == 32 else 0)),
-                        torch.zeros(ops.lib().yolo_conv_cout_pad(cout), device=self.device),
-                        torch.zeros(ops.lib().yolo_conv_cout_pad(cin), device=self.device))
-                self._wbufs[name] = bufs
-            ops.pack_conv_train(conv.weight, bufs[0], bufs[1], cout_pad=cpad)
-            if conv.bias is not None:
-                bufs[2][:cout].copy_(conv.bias.detach())
-            self._wcache[(name, "raw")] = (ver, bufs[0], bufs[2])
-            self._wcache[(name, "dgrad")] = (ver, bufs[1], bufs[3])
-            return self._wcache[key][1], self._wcache[key][2]
+            raise KeyError(f"{name}: trainable layers are packed by _pack_all()")
         self._wcache[key] = (ver, pw, pb)
         return pw, pb
 
@@ -172,14 +246,9 @@ class TrainEngine:
                 if conv.norm is not None:
                     L.z = A(ho, wo, conv.out_channels, 0)
                     L.stats = torch.zeros(5, conv.out_channels, device=dev)
-                    L.dgamma = torch.zeros(conv.out_channels, device=dev)
-                    L.dbeta = torch.zeros(conv.out_channels, device=dev)
                     L.dz = A(ho, wo, conv.out_channels)
-                else:
-                    L.dbias = torch.zeros(conv.out_channels, device=dev)
                 if conv.stride == 2:
                     L.dzd = A(2 * ho, 2 * wo, conv.out_channels)
-                L.dW = torch.zeros(conv.out_channels, conv.kernel_size, conv.kernel_size, conv.in_channels, device=dev)
             P.layers.append(L)
             return L
 
@@ -284,24 +353,25 @@ class TrainEngine:
                 L.dx_accumulate = True
             written.add(kx)
         # every parameter gradient is a view of one flat arena, in the order backward produces them, so that
-        # data-parallel training can all-reduce finished ranges while backward continues (utils/dist.py)
+        # data-parallel training can all-reduce finished ranges while backward continues (utils/dist.py); the arena
+        # belongs to the engine (all plans share it) and the parameters themselves live in its twin
         order = [L for L in reversed(P.layers) if not L.frozen]
-        total = sum(L.dW.numel() + (2 * L.conv.out_channels if L.conv.norm is not None else L.conv.out_channels)
-                    for L in order)
-        P.arena = torch.zeros(total, device=dev)
-        off = 0
+        if self.grad_arena is None:
+            self._adopt(order)
+        assert [L.name for L in order] == self._order
+        P.arena = self.grad_arena
         for L in order:
             c = L.conv
-            L.dW = P.arena[off:off + L.dW.numel()].view(c.out_channels, c.kernel_size, c.kernel_size, c.in_channels)
-            off += L.dW.numel()
+            off, end = self._slots[L.name]
+            n = c.weight.numel()
+            L.dW = P.arena[off:off + n].view(c.out_channels, c.kernel_size, c.kernel_size, c.in_channels)
+            off += n
             if c.norm is not None:
                 L.dgamma = P.arena[off:off + c.out_channels]
                 L.dbeta = P.arena[off + c.out_channels:off + 2 * c.out_channels]
-                off += 2 * c.out_channels
             else:
                 L.dbias = P.arena[off:off + c.out_channels]
-                off += c.out_channels
-            L.arena_end = off
+            L.arena_end = end
         n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
         P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
         n_wg = max(ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
@@ -324,6 +394,7 @@ class TrainEngine:
         """images [N,3,Hs,Ws] uint8/float32 (0..255) on the GPU; returns the head views p3, p4, p5 (f32 NHWC)."""
         N, _, Hs, Ws = images.shape
         P = self.plan(N, (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
+        self._pack_all()
         stem_w, stem_b = self._packed("bottom_up.stem.conv", "folded")
         if P.stem_y is not None:
             dw, db = self._packed("bottom_up.res1.0.downsample", "folded")
