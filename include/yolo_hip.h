@@ -283,6 +283,38 @@ int yolo_dilate2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int
 /* y[i][j] = sum of the 2x2 cell of x: backward of nn.Upsample(2, "nearest") (fpn.py:31,36). */
 int yolo_sum2x2_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
 
+/*
+ * Label assignment + the three training losses for a whole batch, no host read-back.  Replaces
+ * YoloV3Head.forward (yolo/modeling/meta_arch/yolo.py:392-420), _transpose_dense_predictions (:107-109),
+ * label_anchors (:214-264) with pairwise_iou and Matcher.__call__ (yolo/modeling/matcher.py:18-55), losses and
+ * _compute_*_loss (:131-208) and Box2BoxTransform.get_deltas (yolo/modeling/box_regression.py:18-42).
+ *   head[l]     f32 head tensor of level l (0 = finest stride), A*(5+C) channels, as for yolo_decode
+ *   anchors     [R][4] f32 xyxy (device), R = sum over levels of H*W*A, index = level offset + (y*W + x)*A + a
+ *   gt_boxes [N][K][4] f32 xyxy, gt_classes [N][K] i32, gt_count [N] i32 (device): image n has gt_count[n] <= K boxes
+ *   match_thr   anchors whose best IoU exceeds it and that no ground truth picked are ignored (Matcher threshold)
+ *   losses      [3] f32 (device): confidence (obj_weight * mean BCE over positives + noobj_weight * mean BCE over
+ *               negatives), class (mean BCE over positives x C), box (mean smooth-L1 over positives x 4)
+ *   counts_out  NULL or [2] i32 (device): number of positive and of negative anchors in the batch
+ *   workspace   yolo_train_loss_workspace_bytes(N, K, R) bytes; it carries the labels to yolo_train_loss_bwd
+ */
+int yolo_train_loss_fwd(const yolo_view* head, int L, const int* stride_host, const float* anchors, int R, int N,
+                        int A, int C, const float* gt_boxes, const int* gt_classes, const int* gt_count, int K,
+                        float match_thr, float obj_weight, float noobj_weight, float* losses, int* counts_out,
+                        void* workspace, size_t ws_bytes, void* stream);
+size_t yolo_train_loss_workspace_bytes(int N, int K, int R);
+
+/*
+ * Backward of yolo_train_loss_fwd (what autograd derives for the calls listed there): writes
+ * d(sum_i grad_losses[i] * losses[i]) / d(head) into dhead[l] -- every pixel and channel of the views, zeros
+ * included (channels beyond A*(5+C) are zeroed).  Same arguments and the same, untouched workspace as the forward
+ * call;  dhead[l]: bf16 or f32 (dhead_dtype) views of the head's spatial size with >= A*(5+C) channels, a
+ * multiple of 8;  grad_losses: [3] f32 (device).
+ */
+int yolo_train_loss_bwd(const yolo_view* head, const yolo_view* dhead, int dhead_dtype, int L, const int* stride_host,
+                        const float* anchors, int R, int N, int A, int C, const float* gt_boxes,
+                        const int* gt_classes, const int* gt_count, int K, float obj_weight, float noobj_weight,
+                        const float* grad_losses, void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,3 +230,93 @@ def test_param_grads_alias_the_arena_and_still_accumulate(cuda):
     assert eng.param_arena.data_ptr() <= w.data_ptr() < eng.param_arena.data_ptr() + eng.param_arena.numel() * 4
     assert _l2(w.grad, once[id(w)]) < 1e-5
     model.eval()
+
+
+def _torch_losses_on_heads(model, heads_nchw, gt_instances):
+    """The torch-op path of the model (head activations, transposes, label assignment, losses) on given heads."""
+    feats = [h.detach().clone().requires_grad_(True) for h in heads_nchw]
+    losses = model.forward_training(None, feats, model.head(feats), gt_instances)
+    sum(v * w for v, w in zip(losses.values(), (1.0, 0.5, 2.0))).backward()
+    return losses, [f.grad for f in feats]
+
+
+@pytest.mark.parametrize("case", ["random", "empty_image", "shared_anchor"])
+def test_fused_loss_kernels_match_the_torch_ops(cuda, case):
+    """yolo_train_loss_fwd / _bwd against the model's torch-op restatement of the reference's head + label
+    assignment + losses (itself pinned to the oracle on the CPU in tests/test_train_host_cpu.py): the three losses,
+    the positive count and every element of the head gradients, with unequal upstream weights."""
+    from yolo_amd import ops
+    from yolo_amd.structures import Boxes, Instances
+    model, cfg = workload.build_model(config="yolov3.yaml", dtype="f32")
+    C, A, S, N = cfg.MODEL.YOLOV3.NUM_CLASSES, model.num_anchors, 96, 4
+    g = torch.Generator().manual_seed(21)
+    gts = []
+    for n in range(N):
+        k = int(torch.randint(1, 7, (1,), generator=g))
+        if case == "empty_image" and n == 1:
+            k = 0
+        wh = 6 + torch.rand(k, 2, generator=g) * 70
+        xy = torch.rand(k, 2, generator=g) * (S - wh).clamp_min(1)
+        b = torch.cat([xy, xy + wh], 1)
+        c = torch.randint(0, C, (k,), generator=g)
+        if case == "shared_anchor" and n == 0:   # two identical boxes with different classes pick the same anchor
+            b = torch.cat([b, b[:1]])
+            c = torch.cat([c, (c[:1] + 1) % C])
+        gts.append(Instances((S, S), gt_boxes=Boxes(b.to(cuda)), gt_classes=c.to(cuda)))
+    strides = model._get_strides()
+    ak = A * (5 + C)
+    heads = [ops.alloc_view(N, S // s, S // s, (ak + 7) // 8 * 8, 0, torch.float32, cuda) for s in strides]
+    for h in heads:
+        h.buf.normal_(0, 1.5, generator=None)
+    hv = [ops.View(h.buf, h.H, h.W, 0, ak, 0) for h in heads]
+    want, dwant = _torch_losses_on_heads(model, [h.nchw() for h in hv], gts)
+    boxes, classes, counts = model._padded_targets(gts)
+    anchors = Boxes.cat(model.anchor_generator.grid_anchors([(h.H, h.W) for h in heads])).tensor.to(cuda).contiguous()
+    losses, ctx = ops.train_loss_fwd(hv, strides, anchors, boxes, classes.to(torch.int32), counts, num_anchors=A,
+                                     num_classes=C, match_thr=float(model.matcher_threshold),
+                                     obj_weight=float(model.obj_weight), noobj_weight=float(model.noobj_weight))
+    torch.cuda.synchronize()
+    assert int(ctx.counts[0]) == int(model.num_pos_anchors)
+    for got, (name, ref) in zip(losses.tolist(), want.items()):
+        ref = float(ref.detach())
+        assert abs(got - ref) <= 2e-6 * max(1.0, abs(ref)), (name, got, ref)
+    for dt in (torch.float32, torch.bfloat16):
+        cpad = (ak + 63) // 64 * 64
+        dheads = [ops.alloc_view(N, h.H, h.W, cpad, 1, dt, cuda) for h in heads]
+        for d in dheads:
+            d.buf.fill_(7.0)   # stale contents everywhere, halo included
+        ops.train_loss_bwd(ctx, dheads, torch.tensor([1.0, 0.5, 2.0], device=cuda))
+        torch.cuda.synchronize()
+        for d, ref in zip(dheads, dwant):
+            got = d.interior().float()
+            ref = ref.permute(0, 2, 3, 1)
+            tol = 1e-6 if dt == torch.float32 else 4e-3
+            assert float((got[..., :ak] - ref).abs().max()) <= tol * float(ref.abs().max()), dt
+            assert float(got[..., ak:].abs().max()) == 0.0
+            assert float(d.buf[:, 0].min()) == 7.0   # the halo is not written
+
+
+def test_fused_step_equals_the_torch_op_step(cuda):
+    """The model's default training step (fused loss) against the same model with fused_loss off: same losses and
+    the same parameter gradients (f32 plan, so only the loss arithmetic differs)."""
+    model, cfg, sd, imgs, gb, gc, inputs = _make("f32", N=3, S=96)
+    model.train()
+    eng = model.backbone.train_engine()
+    res = {}
+    for fused in (False, True):
+        model.fused_loss = fused
+        for p in model.parameters():
+            p.grad = None
+        model.load_state_dict(sd)   # same running statistics for both runs
+        losses = model(inputs)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        res[fused] = ({k: float(v) for k, v in losses.items()},
+                      {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    for k in res[True][0]:
+        assert abs(res[True][0][k] - res[False][0][k]) <= 1e-5 * max(1.0, abs(res[False][0][k])), k
+    assert len(res[True][1]) == 210 == len(res[False][1])
+    for n, gref in res[False][1].items():
+        assert _l2(res[True][1][n], gref) < 1e-4, n
+    model.fused_loss = True
+    model.eval()

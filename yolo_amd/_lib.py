@@ -48,6 +48,13 @@ SIGNATURES = {
     "yolo_conv2d_wgrad": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                   c_void_p]),
     "yolo_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "yolo_train_loss_fwd": (c_int, [_VP, c_int, ctypes.POINTER(c_int), c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
+    "yolo_train_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "yolo_train_loss_bwd": (c_int, [_VP, _VP, c_int, c_int, ctypes.POINTER(c_int), c_void_p, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
     "yolo_pack_conv_train_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                      c_void_p]),

@@ -82,14 +82,14 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
     const long long m0 = (long long)blockIdx.x * p.chunk;
     const long long m1 = m0 + p.chunk < p.M ? m0 + p.chunk : p.M;
     const int HW = p.H * p.W;
-    for (long long m = m0 + pl; m < m1; m += PL) {
+    // two pixels per iteration, all loads issued before the arithmetic: twice the bytes in flight per thread
+    auto addr = [&](long long m, const char* base, long long origin, long long img, int row, int pix) {
         const int n = (int)(m / HW);
         const int r = (int)(m - (long long)n * HW);
         const int h = r / p.W, w = r - h * p.W;
-        float a[8];
-        load8<T>(p.a + p.a_origin + n * p.a_img_stride + (long long)h * p.a_row_stride + w * p.a_pix_stride +
-                     g * 8 * (int)sizeof(T),
-                 a);
+        return base + origin + n * img + (long long)h * row + w * pix + g * 8 * (int)sizeof(T);
+    };
+    auto accumulate = [&](const float a[8], const float z[8]) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -97,10 +97,6 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
                 s1[e] += a[e] * a[e];
             }
         } else {
-            float z[8];
-            load8<T>(p.z + p.z_origin + n * p.z_img_stride + (long long)h * p.z_row_stride + w * p.z_pix_stride +
-                         g * 8 * (int)sizeof(T),
-                     z);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float pre = z[e] * sc[e] + sh[e];
@@ -109,6 +105,24 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
                 s1[e] += gr * ((z[e] - mu[e]) * is[e]);
             }
         }
+    };
+    long long m = m0 + pl;
+    for (; m + PL < m1; m += 2 * PL) {
+        float a0[8], a1[8], z0[8], z1[8];
+        load8<T>(addr(m, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a0);
+        load8<T>(addr(m + PL, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a1);
+        if constexpr (MODE == 1) {
+            load8<T>(addr(m, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z0);
+            load8<T>(addr(m + PL, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z1);
+        }
+        accumulate(a0, z0);
+        accumulate(a1, z1);
+    }
+    if (m < m1) {
+        float a0[8], z0[8];
+        load8<T>(addr(m, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a0);
+        if constexpr (MODE == 1) load8<T>(addr(m, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z0);
+        accumulate(a0, z0);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -146,25 +160,48 @@ struct FinParams {
     float* dbeta;
 };
 
-// One workgroup per 8 channels: 32 thread groups stride over the partial blocks (double precision), then fold
-// through LDS, so the serial chain per thread is blocks/32 loads instead of blocks.
+// One workgroup per 8 channels: 128 thread groups stride over the partial blocks (double precision, two independent
+// chains per thread), then fold through LDS, so the serial chain per thread is blocks/256 loads instead of blocks.
 template <int MODE>
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const FinParams p) {
-    __shared__ double sa[32][8], sb[32][8];
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const FinParams p) {
+    constexpr int NG = 128;
+    __shared__ double sa[NG][8], sb[NG][8];
     const int cl = threadIdx.x & 7, j = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
     if (c < p.C) {
-        for (int i = j; i < p.blocks; i += 32) {
+        int i = j;
+        for (; i + NG < p.blocks; i += 2 * NG) {
+            const float x0 = p.partial[((long long)i * 2 + 0) * p.C + c], y0 = p.partial[((long long)i * 2 + 1) * p.C + c];
+            const float x1 = p.partial[((long long)(i + NG) * 2 + 0) * p.C + c];
+            const float y1 = p.partial[((long long)(i + NG) * 2 + 1) * p.C + c];
+            a += (double)x0;
+            b += (double)y0;
+            a2 += (double)x1;
+            b2 += (double)y1;
+        }
+        if (i < p.blocks) {
             a += (double)p.partial[((long long)i * 2 + 0) * p.C + c];
             b += (double)p.partial[((long long)i * 2 + 1) * p.C + c];
         }
+        a += a2;
+        b += b2;
     }
     sa[j][cl] = a;
     sb[j][cl] = b;
     __syncthreads();
+    // fold 128 -> 8 groups in parallel, then the last 8 serially
+    if (j < 8) {
+        for (int k = j + 8; k < NG; k += 8) {
+            a += sa[k][cl];
+            b += sb[k][cl];
+        }
+        sa[j][cl] = a;
+        sb[j][cl] = b;
+    }
+    __syncthreads();
     if (j != 0 || c >= p.C) return;
-    for (int k = 1; k < 32; ++k) {
+    for (int k = 1; k < 8; ++k) {
         a += sa[k][cl];
         b += sb[k][cl];
     }
@@ -375,7 +412,7 @@ extern "C" int yolo_bn_train_stats(const yolo_view* z, int N, int C, int dtype, 
     f.shift = stats + 4 * C;
     f.running_mean = running_mean;
     f.running_var = running_var;
-    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((C + 7) / 8), dim3(256), 0, st, f);
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((C + 7) / 8), dim3(1024), 0, st, f);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }
@@ -483,7 +520,7 @@ extern "C" int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const fl
     f.count = (double)r.M;
     f.dgamma = dgamma;
     f.dbeta = dbeta;
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((C + 7) / 8), dim3(256), 0, st, f);
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((C + 7) / 8), dim3(1024), 0, st, f);
     ApplyParams p{};
     fill_apply(p, z, dy, dz, N, C, es);
     p.mean = stats;

@@ -142,13 +142,16 @@ class DarkNetFPN(Backbone):
                                              dtype=self.compute_dtype)
         return self._train_engine
 
+    def trainable_named_parameters(self):
+        return [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+
     def forward_train(self, images: torch.Tensor, mean, std) -> Dict[str, torch.Tensor]:
         """Training-mode forward on raw images [N,3,Hs,Ws] (0..255, uint8 or float32, on the GPU): batch-statistics
         BatchNorm in the trainable stages, frozen stages as in inference.  Returns {"p3","p4","p5"} float32 head
         tensors attached to the autograd graph: ``loss.backward()`` runs the HIP backward plan and leaves the
         gradients in the parameters' ``.grad``."""
         eng = self.train_engine()
-        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        named = self.trainable_named_parameters()
         outs = _TrainFunction.apply(eng, images, tuple(mean), tuple(std), named, *[p for _, p in named])
         return dict(zip(self._out_features, outs))
 
@@ -192,32 +195,37 @@ class _TrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dheads):
-        """Runs the backward plan, which leaves every parameter gradient in the engine's gradient arena, laid out
-        like the parameters.  A parameter without a gradient gets its arena slice AS its ``.grad`` (no copy; the
-        usual zero_grad() -> backward() -> step() loop always takes this route).  A ``.grad`` that already is the
-        arena slice keeps accumulation semantics: what it held is added back.  Any other ``.grad`` tensor is left
-        to autograd, which adds the returned gradient to it."""
-        eng = ctx.eng
         dheads = [d if d is not None else torch.zeros_like(h.nchw()) for d, h in zip(dheads, ctx.plan.heads)]
-        views = {id(p): g for p, g in eng.grad_views()}
-        held = [(p, p.grad.clone()) for _, p in ctx.named
-                if p.grad is not None and id(p) in views and p.grad.data_ptr() == views[id(p)].data_ptr()]
-        eng.backward(ctx.plan, dheads)
-        out = []
-        for _, p in ctx.named:
-            g = views.get(id(p))
-            if g is None:
-                out.append(None)
-            elif p.grad is None:
-                p.grad = g
-                out.append(None)
-            elif p.grad.data_ptr() == g.data_ptr():
-                out.append(None)
-            else:
-                out.append(g)
-        for p, old in held:
-            p.grad.add_(old)
-        return (None, None, None, None, None) + tuple(out)
+        out = install_param_grads(ctx.eng, ctx.named, lambda: ctx.eng.backward(ctx.plan, dheads))
+        return (None, None, None, None, None) + out
+
+
+def install_param_grads(eng, named, run_backward) -> tuple:
+    """``run_backward()`` runs the engine's backward plan, which leaves every parameter gradient in the engine's
+    gradient arena, laid out like the parameters.  A parameter without a gradient gets its arena slice AS its
+    ``.grad`` (no copy; the usual zero_grad() -> backward() -> step() loop always takes this route).  A ``.grad``
+    that already is the arena slice keeps accumulation semantics: what it held is added back.  Any other ``.grad``
+    tensor is left to autograd: the returned tuple (one entry per parameter of ``named``) carries the gradient
+    for exactly those parameters and None for the rest."""
+    views = {id(p): g for p, g in eng.grad_views()}
+    held = [(p, p.grad.clone()) for _, p in named
+            if p.grad is not None and id(p) in views and p.grad.data_ptr() == views[id(p)].data_ptr()]
+    run_backward()
+    out = []
+    for _, p in named:
+        g = views.get(id(p))
+        if g is None:
+            out.append(None)
+        elif p.grad is None:
+            p.grad = g
+            out.append(None)
+        elif p.grad.data_ptr() == g.data_ptr():
+            out.append(None)
+        else:
+            out.append(g)
+    for p, old in held:
+        p.grad.add_(old)
+    return tuple(out)
 
 
 @BACKBONE_REGISTRY.register()

@@ -50,6 +50,40 @@ class YoloV3Head(nn.Module):
         return pred_logits, pred_confs, pred_deltas
 
 
+class _FusedTrainStep(torch.autograd.Function):
+    """Backbone + neck + heads + label assignment + losses as ONE autograd node: torch sees the trainable
+    parameters going in and three scalar losses coming out (plus the positive-anchor count, not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, eng, images, mean, std, named, gt_boxes, gt_classes, gt_count, cfgd, *params):
+        from ... import ops
+        heads = eng.forward(images, mean, std)
+        N, _, Hs, Ws = images.shape
+        ctx.eng, ctx.named = eng, named
+        ctx.plan = eng.plan(N, (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
+        losses, ctx.loss_ctx = ops.train_loss_fwd(heads, cfgd["strides"], cfgd["anchors"], gt_boxes, gt_classes, gt_count,
+                                                  num_anchors=cfgd["num_anchors"], num_classes=cfgd["num_classes"],
+                                                  match_thr=cfgd["match_thr"], obj_weight=cfgd["obj_weight"],
+                                                  noobj_weight=cfgd["noobj_weight"])
+        n_pos = ctx.loss_ctx.counts[0]
+        ctx.mark_non_differentiable(n_pos)
+        return losses[0], losses[1], losses[2], n_pos
+
+    @staticmethod
+    def backward(ctx, g_conf, g_cls, g_box, _g_npos):
+        from ... import ops
+        from ..backbone.fpn import install_param_grads
+        dev = ctx.loss_ctx.anchors.device
+        gs = torch.stack([g if g is not None else torch.zeros((), device=dev) for g in (g_conf, g_cls, g_box)]).float()
+
+        def run():
+            ops.train_loss_bwd(ctx.loss_ctx, ctx.plan.dheads, gs)
+            ctx.eng.backward(ctx.plan, None)
+
+        out = install_param_grads(ctx.eng, ctx.named, run)
+        return (None,) * 9 + out
+
+
 class YOLOV3(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -61,6 +95,7 @@ class YOLOV3(nn.Module):
         num_anchors = self.anchor_generator.num_cell_anchors
         assert len(set(num_anchors)) == 1, "Using different number of anchors between levels is not currently supported!"
         self.num_classes = cfg.MODEL.YOLOV3.NUM_CLASSES
+        self.num_anchors = num_anchors[0]
         self.head = YoloV3Head(num_anchors=num_anchors[0], num_classes=self.num_classes)
         self.box2box_transform = Box2BoxTransform((1.0, 1.0, 1.0, 1.0), 0.5)
         self.test_score_thresh = cfg.MODEL.YOLOV3.TEST_SCORE_THRESH
@@ -68,6 +103,8 @@ class YOLOV3(nn.Module):
         self.test_topk_candidates = 1000  # stored, unused (as in the reference, yolo.py:45,61)
         self.max_detections_pre_image = 100
         self.obj_weight, self.noobj_weight = 1, 100
+        self.fused_loss = True     # training: label assignment + losses as HIP kernels (False: the torch ops below)
+        self._anchor_cache: Dict = {}
         self.matcher_threshold = cfg.MODEL.MATCHER.IGNORE_THRESHOLD
         self.matcher_labels = list(cfg.MODEL.MATCHER.LABELS)
         self.anchor_matcher = Matcher(threshold=self.matcher_threshold, labels=self.matcher_labels,
@@ -124,10 +161,48 @@ class YOLOV3(nn.Module):
         assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
         batch, _ = self._batch_images(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        if self.fused_loss and list(self.matcher_labels) == [-1, 0, 1]:
+            return self._fused_training_step(batch, gt_instances)
         feats = self.backbone.forward_train(batch, self._mean, self._std)
         features = [feats[f] for f in self.head_in_features]
         predictions = self.head(features)
         return self.forward_training(batch, features, predictions, gt_instances)
+
+    def _padded_targets(self, gt_instances: List[Instances]):
+        """Ground truths of a batch as [N,K,4] boxes, [N,K] classes and [N] counts (K = the batch maximum, >= 1)."""
+        dev = self.device
+        lens = [len(g) for g in gt_instances]
+        N, K = len(lens), max(max(lens), 1)
+        boxes = torch.zeros(N, K, 4, device=dev)
+        classes = torch.zeros(N, K, dtype=torch.int64, device=dev)
+        if sum(lens):  # one scatter for the whole batch instead of slice copies per image
+            n_of = torch.tensor([n for n, k in enumerate(lens) for _ in range(k)], device=dev)
+            k_of = torch.tensor([j for k in lens for j in range(k)], device=dev)
+            boxes[n_of, k_of] = torch.cat([g.gt_boxes.tensor for g in gt_instances]).to(boxes.dtype)
+            classes[n_of, k_of] = torch.cat([g.gt_classes for g in gt_instances])
+        return boxes, classes, torch.tensor(lens, dtype=torch.int32, device=dev)
+
+    def _fused_training_step(self, batch: torch.Tensor, gt_instances: List[Instances]) -> Dict[str, torch.Tensor]:
+        """Forward plan -> one fused label-assignment + loss call on the raw head tensors; backward: the loss
+        gradient kernel writes the head gradients where the backward plan reads them.  No torch op touches a head
+        tensor and nothing is read back to the host."""
+        bb = self.backbone
+        eng = bb.train_engine()
+        named = bb.trainable_named_parameters()
+        boxes, classes, counts = self._padded_targets(gt_instances)
+        N, _, Hs, Ws = batch.shape
+        H, W = (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32
+        key = (H, W)
+        if key not in self._anchor_cache:
+            grids = [(H // s, W // s) for s in self._get_strides()]
+            self._anchor_cache[key] = Boxes.cat(self.anchor_generator.grid_anchors(grids)).tensor.to(self.device).contiguous()
+        cfgd = dict(anchors=self._anchor_cache[key], strides=self._get_strides(), num_anchors=self.num_anchors,
+                    num_classes=self.num_classes, match_thr=float(self.matcher_threshold),
+                    obj_weight=float(self.obj_weight), noobj_weight=float(self.noobj_weight))
+        conf, cls, box, n_pos = _FusedTrainStep.apply(eng, batch, tuple(self._mean), tuple(self._std), named, boxes,
+                                                     classes.to(torch.int32), counts, cfgd, *[p for _, p in named])
+        self.num_pos_anchors = n_pos
+        return {"confs_loss": conf, "logits_loss": cls, "regression_loss": box}
 
     @staticmethod
     def _transpose_dense_predictions(predictions, dims_per_anchor: List[int]):
@@ -190,15 +265,9 @@ class YOLOV3(nn.Module):
         masked.  Same rules as Matcher.__call__ (matcher.py:18-48); returns per-image lists like label_anchors."""
         a = Boxes.cat(anchors).tensor                                   # [R, 4]
         N, dev = len(gt_instances), a.device
-        K = max(max(len(g) for g in gt_instances), 1)
-        boxes = torch.zeros(N, K, 4, device=dev)
-        classes = torch.zeros(N, K, dtype=torch.int64, device=dev)
-        valid = torch.zeros(N, K, dtype=torch.bool, device=dev)
-        for n, g in enumerate(gt_instances):
-            k = len(g)
-            boxes[n, :k] = g.gt_boxes.tensor
-            classes[n, :k] = g.gt_classes
-            valid[n, :k] = True
+        boxes, classes, counts = self._padded_targets(gt_instances)
+        K = boxes.shape[1]
+        valid = torch.arange(K, device=dev)[None, :] < counts[:, None]
         area_g = (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])          # [N, K]
         area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])                                  # [R]
         wh = (torch.min(boxes[:, :, None, 2:], a[None, None, :, 2:]) -

@@ -457,3 +457,67 @@ def pack_conv_train_batch(table: torch.Tensor, n_layers: int, total_tiles: int, 
     _require_cuda(table, "pack_conv_train_batch")
     check(lib().yolo_pack_conv_train_batch(_ptr(table), n_layers, total_tiles, dtype_code(dtype), _stream()),
           "yolo_pack_conv_train_batch")
+
+
+def _view_array(views):
+    arr = (YoloView * len(views))()
+    for i, v in enumerate(views):
+        arr[i] = v.c()
+    return arr
+
+
+@dataclass
+class LossContext:
+    """What train_loss_fwd leaves for train_loss_bwd: the call's arguments and the workspace holding the labels."""
+    heads: list
+    strides: list
+    anchors: torch.Tensor
+    gt_boxes: torch.Tensor
+    gt_classes: torch.Tensor
+    gt_count: torch.Tensor
+    A: int
+    C: int
+    obj_weight: float
+    noobj_weight: float
+    ws: torch.Tensor
+    counts: torch.Tensor
+
+
+def train_loss_fwd(heads: Sequence[View], strides: Sequence[int], anchors: torch.Tensor, gt_boxes: torch.Tensor,
+                   gt_classes: torch.Tensor, gt_count: torch.Tensor, *, num_anchors: int, num_classes: int,
+                   match_thr: float, obj_weight: float, noobj_weight: float):
+    """Label assignment + the three losses of a batch in a handful of launches, nothing read back.
+    heads: f32 head views (finest stride first); anchors [R,4] f32; gt_boxes [N,K,4] f32, gt_classes [N,K] i32,
+    gt_count [N] i32.  Returns (losses [3] f32: confidence, class, box; LossContext)."""
+    _require_cuda(anchors, "train_loss_fwd")
+    N, K = gt_classes.shape
+    R = anchors.shape[0]
+    assert anchors.dtype == torch.float32 and anchors.is_contiguous() and anchors.shape[1] == 4
+    assert gt_boxes.dtype == torch.float32 and gt_boxes.is_contiguous() and gt_boxes.shape == (N, K, 4)
+    assert gt_classes.dtype == torch.int32 and gt_classes.is_contiguous()
+    assert gt_count.dtype == torch.int32 and gt_count.shape == (N,)
+    assert all(h.buf.dtype == torch.float32 and h.N == N for h in heads)
+    dev = anchors.device
+    ws = torch.empty(lib().yolo_train_loss_workspace_bytes(N, K, R), dtype=torch.uint8, device=dev)
+    losses = torch.empty(3, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    st = (ctypes.c_int * len(strides))(*strides)
+    check(lib().yolo_train_loss_fwd(_view_array(heads), len(heads), st, _ptr(anchors), R, N, num_anchors, num_classes,
+                                    _ptr(gt_boxes), _ptr(gt_classes), _ptr(gt_count), K, match_thr, obj_weight,
+                                    noobj_weight, _ptr(losses), _ptr(counts), _ptr(ws), ws.numel(), _stream()),
+          "yolo_train_loss_fwd")
+    ctx = LossContext(list(heads), list(strides), anchors, gt_boxes, gt_classes, gt_count, num_anchors, num_classes,
+                      obj_weight, noobj_weight, ws, counts)
+    return losses, ctx
+
+
+def train_loss_bwd(ctx: LossContext, dheads: Sequence[View], grad_losses: torch.Tensor) -> None:
+    """Writes d(sum_i grad_losses[i] * loss_i)/d(head) into the gradient views (every element, zeros included)."""
+    assert grad_losses.dtype == torch.float32 and grad_losses.numel() == 3 and grad_losses.is_cuda
+    N, K = ctx.gt_classes.shape
+    st = (ctypes.c_int * len(ctx.strides))(*ctx.strides)
+    check(lib().yolo_train_loss_bwd(_view_array(ctx.heads), _view_array(dheads), dtype_code(dheads[0].buf.dtype),
+                                    len(ctx.heads), st, _ptr(ctx.anchors), ctx.anchors.shape[0], N, ctx.A, ctx.C,
+                                    _ptr(ctx.gt_boxes), _ptr(ctx.gt_classes), _ptr(ctx.gt_count), K, ctx.obj_weight,
+                                    ctx.noobj_weight, _ptr(grad_losses.contiguous()), _ptr(ctx.ws), ctx.ws.numel(),
+                                    _stream()), "yolo_train_loss_bwd")

@@ -426,13 +426,16 @@ class TrainEngine:
         return P.heads
 
     # ------------------------------------------------------------------ backward
-    def backward(self, P: TPlan, dheads: Sequence[torch.Tensor]) -> None:
-        """dheads: gradients of the loss w.r.t. the head tensors p3, p4, p5 as [N, A*(5+C), G, G] (any strides).
-        Fills L.dW / dgamma / dbeta / dbias of every trainable layer."""
+    def backward(self, P: TPlan, dheads: Optional[Sequence[torch.Tensor]]) -> None:
+        """dheads: gradients of the loss w.r.t. the head tensors p3, p4, p5 as [N, A*(5+C), G, G] (any strides), or
+        None when P.dheads already hold them (written by ops.train_loss_bwd).  Fills L.dW / dgamma / dbeta / dbias
+        of every trainable layer."""
         ak = (5 + self.num_classes) * self.num_anchors
-        for dv, g in zip(P.dheads, dheads):
-            dv.interior()[..., :ak].copy_(g.permute(0, 2, 3, 1))
-        head_grad = {id(dv.buf): g for dv, g in zip(P.dheads, dheads)}
+        head_grad = {}
+        if dheads is not None:
+            for dv, g in zip(P.dheads, dheads):
+                dv.interior()[..., :ak].copy_(g.permute(0, 2, 3, 1))
+            head_grad = {id(dv.buf): g for dv, g in zip(P.dheads, dheads)}
         import torch.distributed as dist
         ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
         if ddp:
@@ -445,7 +448,11 @@ class TrainEngine:
                 continue
             c = L.conv
             if c.norm is None:
-                L.dbias.copy_(head_grad[id(L.dz.buf)].sum(dim=(0, 2, 3)))
+                g = head_grad.get(id(L.dz.buf))
+                if g is not None:
+                    L.dbias.copy_(g.sum(dim=(0, 2, 3)))
+                else:
+                    torch.sum(L.dz.interior()[..., :ak], dim=(0, 1, 2), dtype=torch.float32, out=L.dbias)
             else:
                 if L.up_src is not None:
                     ops.sum2x2(L.up_src, L.dy)
