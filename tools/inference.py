@@ -61,7 +61,9 @@ class Predictor:
             original_image = original_image[:, :, ::-1]
         height, width = original_image.shape[:2]
         image = resize_shortest_edge(np.ascontiguousarray(original_image), self.min_size, self.max_size)
-        image = torch.as_tensor(image.astype("float32").transpose(2, 0, 1))
+        # the reference converts to float32 on the host (tools/inference.py:42); the bytes go up as they are (a
+        # quarter of the transfer) and the stem kernel does the conversion -- same values, 0..255
+        image = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
         return self.model([dict(height=height, width=width, image=image)])[0]
 
 
