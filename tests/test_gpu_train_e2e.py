@@ -320,3 +320,39 @@ def test_fused_step_equals_the_torch_op_step(cuda):
         assert _l2(res[True][1][n], gref) < 1e-4, n
     model.fused_loss = True
     model.eval()
+
+
+def test_fused_loss_kernels_match_the_oracle_golden(cuda):
+    """The HIP loss kernels against the committed vectors of the training oracle
+    (tests/golden/oracle_train_golden.npz: seeded heads, ground truths incl. two sharing one anchor)."""
+    import os
+    import numpy as np
+    from yolo_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_train_golden.npz"))
+    C, A, strides, N = 20, 3, [8, 16, 32], 3
+    ak = A * (5 + C)
+    heads = []
+    for i in range(3):
+        h = torch.from_numpy(g[f"head{i}"]).to(cuda)
+        v = ops.alloc_view(N, h.shape[2], h.shape[3], (ak + 7) // 8 * 8, 0, torch.float32, cuda)
+        v.interior()[..., :ak] = h.permute(0, 2, 3, 1)
+        heads.append(ops.View(v.buf, v.H, v.W, 0, ak, 0))
+    gb = [torch.from_numpy(g[f"gt_boxes{n}"]) for n in range(N)]
+    gc = [torch.from_numpy(g[f"gt_classes{n}"]) for n in range(N)]
+    K = max(len(b) for b in gb)
+    boxes, classes = torch.zeros(N, K, 4), torch.zeros(N, K, dtype=torch.int32)
+    for n in range(N):
+        boxes[n, :len(gb[n])], classes[n, :len(gb[n])] = gb[n], gc[n].to(torch.int32)
+    counts = torch.tensor([len(b) for b in gb], dtype=torch.int32)
+    from oracle import yolo_ref as R
+    anchors = torch.cat(R.grid_anchors([(h.H, h.W) for h in heads], strides)).to(cuda).contiguous()
+    losses, ctx = ops.train_loss_fwd(heads, strides, anchors, boxes.to(cuda), classes.to(cuda), counts.to(cuda),
+                                     num_anchors=A, num_classes=C, match_thr=0.5, obj_weight=1.0, noobj_weight=100.0)
+    lab = g["labels"]
+    assert ctx.counts.tolist() == [int(((lab >= 0) & (lab < C)).sum()), int((lab == C).sum())]
+    assert np.allclose(losses.cpu().numpy(), g["losses"], rtol=2e-6)
+    dheads = [ops.alloc_view(N, h.H, h.W, 128, 1, torch.float32, cuda) for h in heads]
+    ops.train_loss_bwd(ctx, dheads, torch.tensor([1.0, 0.5, 2.0], device=cuda))
+    for i, d in enumerate(dheads):
+        ref = torch.from_numpy(g[f"dhead{i}"]).permute(0, 2, 3, 1)
+        assert float((d.interior()[..., :ak].cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
