@@ -16,8 +16,11 @@
 // (split-K); partial tiles go to fp32 slabs, a second kernel adds the slabs.  Rows past the end of the pixel
 // range are fetched from a zero pixel of dz's halo, so they add nothing.
 //
-// Two ways to walk the pixels.  GATHER: k = output pixel (n, ho, wo), each tile row's address from two integer
+// Three ways to walk the pixels.  GATHER: k = output pixel (n, ho, wo), each tile row's address from two integer
 // divisions -- about 300 vector instructions per k-step against 32 MFMAs, which is what bounds that form.
+// CURSORS (the default): the same k, but the divisions happen once per workgroup; after that each lane advances
+// (wo, ho, two 32-bit byte offsets) of its four tile rows by 64 pixels per k-step with one row carry and one
+// image wrap at most (needs 64 / Wo + 1 <= Ho and buffers below 4 GiB).
 // LINEAR (stride 1, x and dz buffers of identical geometry, zero halo in dz): k = position in the halo'd
 // buffer, halo pixels included; dz is zero there, so they add nothing, x[k + tap offset] is always inside the
 // buffer, and every address is base + k * pixel stride.  Images are walked in segments of G consecutive
@@ -45,6 +48,10 @@ struct WgradParams {
     // (x_first: of tap (pad, pad)) and from one segment to the next
     int lin_len, lin_sps, total_steps, pad;
     long long dz_first, x_first, dz_seg_stride, x_seg_stride;
+    // cursor mode: 64 pixels = adv_rows rows + adv_cols columns; byte-offset increments (mod 2^32) of that
+    // advance, of a row carry (next row, Wo columns back) and of an image wrap (next image, Ho rows back)
+    int adv_rows, adv_cols;
+    unsigned adv_a, adv_b, carry_a, carry_b, wrap_a, wrap_b;
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -64,8 +71,12 @@ __device__ __forceinline__ void divmod(int m, int d, float inv, int& q, int& r) 
 
 // NARROW (Cin <= 64): the 4 waves split the 128 output channels four ways and each covers the 64 live input
 // channels, instead of 2 x 2 waves of 64 x 64 -- no matrix-core work on the dead half of the ci tile.
-template <bool NARROW, bool LINEAR>
+// MODE: 0 = gather with divisions, 1 = linear walk, 2 = gather with cursors (one division per tile row per
+// workgroup, then (wo, ho, byte offsets) advance by 64 pixels per k-step with at most one row carry and one image
+// wrap -- which holds when 64 / Wo + 1 <= Ho and the buffers are addressable with 32 bits)
+template <bool NARROW, int MODE>
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
+    constexpr bool LINEAR = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 16 KiB + B 16 KiB)
     constexpr int KT = 64;            // pixels per k-step: two 16x16x32 MFMA slabs per barrier
     constexpr int TILE = KT * 256;
@@ -108,7 +119,56 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         tap_off = (long long)(kh - p.pad) * p.x_row_stride + (long long)(kw - p.pad) * p.x_pix_stride;
     }
 
+    // MODE 2 cursors of this lane's four tile rows
+    int c_wo[KT / 16], c_ho[KT / 16];
+    unsigned c_a[KT / 16], c_b[KT / 16];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < KT / 16; ++j) {
+            int m = m_begin + row0 + 16 * j;
+            m = m < p.M ? m : 0;   // rows past the end are never dereferenced (and never advance past M)
+            int n, r;
+            divmod(m, p.HoWo, p.inv_HoWo, n, r);
+            divmod(r, p.Wo, p.inv_Wo, c_ho[j], c_wo[j]);
+            c_a[j] = (unsigned)(p.dz_origin + n * p.dz_img_stride + (long long)c_ho[j] * p.dz_row_stride +
+                                (long long)c_wo[j] * p.dz_pix_stride + a_ch * 2);
+            c_b[j] = (unsigned)(p.x_origin + n * p.x_img_stride + (long long)(c_ho[j] * p.stride) * p.x_row_stride +
+                                (long long)(c_wo[j] * p.stride) * p.x_pix_stride + x_tap + b_ch * 2);
+        }
+    }
+
     auto stage = [&](int step, char* buf) {
+        if constexpr (MODE == 2) {
+            const int m0 = m_begin + step * KT + row0;
+#pragma unroll
+            for (int j = 0; j < KT / 16; ++j) {
+                const bool ok = m0 + 16 * j < m_end;
+                const char* a = p.dz + (ok ? c_a[j] : (unsigned)(p.dz_zero + (a_ch & 127) * 2));
+                const char* b = p.x + (ok ? c_b[j] : (unsigned)(p.x_origin + x_tap + b_ch * 2));
+                char* la = buf + (16 * j + 4 * wave) * 256;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                                 (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b,
+                                                 (__attribute__((address_space(3))) void*)(la + TILE), 16, 0, 0);
+                // advance by 64 pixels = adv_rows rows + adv_cols columns
+                int wo = c_wo[j] + p.adv_cols, ho = c_ho[j] + p.adv_rows;
+                unsigned oa = c_a[j] + p.adv_a, ob = c_b[j] + p.adv_b;
+                const bool carry = wo >= p.Wo;
+                wo -= carry ? p.Wo : 0;
+                ho += carry ? 1 : 0;
+                oa += carry ? p.carry_a : 0u;
+                ob += carry ? p.carry_b : 0u;
+                const bool wrap = ho >= p.Ho;
+                ho -= wrap ? p.Ho : 0;
+                oa += wrap ? p.wrap_a : 0u;
+                ob += wrap ? p.wrap_b : 0u;
+                c_wo[j] = wo;
+                c_ho[j] = ho;
+                c_a[j] = oa;
+                c_b[j] = ob;
+            }
+            return;
+        }
         if constexpr (LINEAR) {
             const long long ua = (long long)seg * p.dz_seg_stride + (long long)t * (KT * p.dz_pix_stride);
             const long long ub = (long long)seg * p.x_seg_stride + (long long)t * (KT * p.x_pix_stride);
@@ -483,20 +543,38 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     p.slab = (long long)Cout * k * k * Cin;
     const long long max_splits = (long long)(ws_bytes / ((size_t)p.slab * sizeof(float)));
     YOLO_REQUIRE(max_splits >= 1, "conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, (size_t)p.slab * sizeof(float));
-    // same geometry on both sides and a (zero) halo in dz: walk the halo'd buffers linearly
-    static const bool allow_linear = !(getenv("YOLO_WGRAD_GATHER") && atoi(getenv("YOLO_WGRAD_GATHER")));
-    const bool linear = allow_linear && stride == 1 && x->halo == dz->halo && dz->halo >= 1 && x->H == dz->H && x->W == dz->W;
+    // Which walk: linear needs the same geometry on both sides and a (zero) halo in dz, and walks the halo too;
+    // cursors need images at least 64 / Wo + 1 rows high and 32-bit byte offsets; divisions always work.
+    static const int force_mode = getenv("YOLO_WGRAD_MODE") ? atoi(getenv("YOLO_WGRAD_MODE")) : -1;
+    const bool can_linear = stride == 1 && x->halo == dz->halo && dz->halo >= 1 && x->H == dz->H && x->W == dz->W;
+    const long long x_bytes = (long long)N * gx.img_stride * 2, dz_bytes = (long long)N * gd.img_stride * 2;
+    const bool can_cursor = 64 / Wo + 1 <= Ho && x_bytes < (1ll << 32) && dz_bytes < (1ll << 32);
     int steps = ((int)M + 63) / 64;
-    if (linear) {
-        int G = 1;
+    int G = 1, lin_steps = 0;
+    if (can_linear) {
         wgrad_linear_plan(N, Ho, Wo, dz->halo, &G, &p.lin_len, &p.lin_sps);
-        p.total_steps = p.lin_sps * (N / G);
+        lin_steps = p.lin_sps * (N / G);
+    }
+    // cursors measured equal or faster than the linear walk on every layer shape (no halo positions to walk)
+    int mode = can_cursor ? 2 : (can_linear ? 1 : 0);
+    if (force_mode == 0 || (force_mode == 1 && can_linear) || (force_mode == 2 && can_cursor)) mode = force_mode;
+    if (mode == 1) {
+        p.total_steps = lin_steps;
         p.pad = pad;
         p.dz_first = (long long)gd.origin * 2;
         p.x_first = (long long)gx.origin * 2;
         p.dz_seg_stride = (long long)G * p.dz_img_stride;
         p.x_seg_stride = (long long)G * p.x_img_stride;
         steps = p.total_steps;
+    } else if (mode == 2) {
+        p.adv_rows = 64 / Wo;
+        p.adv_cols = 64 % Wo;
+        p.adv_a = (unsigned)((long long)p.adv_rows * p.dz_row_stride + (long long)p.adv_cols * p.dz_pix_stride);
+        p.adv_b = (unsigned)(((long long)p.adv_rows * p.x_row_stride + (long long)p.adv_cols * p.x_pix_stride) * stride);
+        p.carry_a = (unsigned)((long long)p.dz_row_stride - (long long)Wo * p.dz_pix_stride);
+        p.carry_b = (unsigned)(((long long)p.x_row_stride - (long long)Wo * p.x_pix_stride) * stride);
+        p.wrap_a = (unsigned)(p.dz_img_stride - (long long)Ho * p.dz_row_stride);
+        p.wrap_b = (unsigned)(p.x_img_stride - (long long)Ho * stride * p.x_row_stride);
     }
     wgrad_plan(steps, Cin, Cout, k, max_splits, &p.n_mt, &p.n_nt, &p.splits, &p.steps_per_split);
     p.out = (float*)workspace;
@@ -504,15 +582,19 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     constexpr int LDS = 2 * 2 * 64 * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
-    auto kern = Cin <= 64 ? (linear ? wgrad_kernel<true, true> : wgrad_kernel<true, false>)
-                          : (linear ? wgrad_kernel<false, true> : wgrad_kernel<false, false>);
+    const bool narrow = Cin <= 64;
+    auto kern = mode == 1 ? (narrow ? wgrad_kernel<true, 1> : wgrad_kernel<false, 1>)
+              : mode == 2 ? (narrow ? wgrad_kernel<true, 2> : wgrad_kernel<false, 2>)
+                          : (narrow ? wgrad_kernel<true, 0> : wgrad_kernel<false, 0>);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, st, p);
     launch_wgrad_reduce(workspace, dw, p.slab, p.splits, accumulate, st);
     YOLO_CHECK_HIP(hipGetLastError());
