@@ -227,6 +227,22 @@ int yolo_bn_train_stats(const yolo_view* z, int N, int C, int dtype, const float
                         void* workspace, size_t ws_bytes, void* stream);
 size_t yolo_bn_workspace_bytes(int N, int H, int W, int C);
 
+/*
+ * The same convolution as yolo_conv2d_fwd (linear, no residual, output type = operand type) that also leaves
+ * the first pass of the following training-mode BatchNorm (detectron2 Conv2d.forward: F.conv2d, then self.norm):
+ *   sums  [rows][2][Cout] f32, rows = yolo_conv2d_bnsums_rows(N*Ho*Wo, Cout): per pixel tile and channel, the sum
+ *         of the output values as stored and of their squares
+ * yolo_bn_train_finalize turns the rows into what yolo_bn_train_stats writes (stats [5][C], running statistics);
+ * count = N*Ho*Wo.  Together they replace yolo_conv2d_fwd + yolo_bn_train_stats without re-reading z.
+ */
+int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* y,
+                           int N, int Cin, int Cout, int k, int stride, int dtype, float* sums,
+                           size_t sums_bytes, void* stream);
+int yolo_conv2d_bnsums_rows(int M, int Cout);
+int yolo_bn_train_finalize(const float* sums, int rows, long long count, int C, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, float* stats, void* stream);
+
 /* y = leaky(z*scale + shift) [+ residual]: BatchNorm2d (training) + F.leaky_relu (darknet.py:59,116,120,123;
  * fpn.py:35,69,98) + `out += residual` (darknet.py:125).  stats from yolo_bn_train_stats. */
 int yolo_bn_act_fwd(const yolo_view* z, const float* stats, const yolo_view* residual, const yolo_view* y,

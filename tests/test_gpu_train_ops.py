@@ -185,3 +185,39 @@ def test_pack_conv_train_batch(cuda, dtype):
         wpad[:cout] = w
         want_d, _ = ops.pack_conv_dgrad(wpad, dtype, cuda)
         assert torch.equal(dg[:cin].float().cpu(), want_d[:cin, :k * k * cpad].float().cpu()), (cout, cin, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 128, 3, 1, 20, 12), (2, 128, 64, 1, 1, 13, 13), (2, 64, 256, 3, 2, 16, 16),
+                                   (5, 128, 256, 1, 1, 9, 7)], ids=lambda s: "x".join(map(str, s)))
+def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
+    """yolo_conv2d_fwd_bnsums + yolo_bn_train_finalize against yolo_conv2d_fwd + yolo_bn_train_stats: the same z
+    bit for bit, the same statistics (sums of the stored z, folded in fp64 in both) and running-stat update."""
+    from yolo_amd import ops
+    N, cin, cout, k, s, H, W = shape
+    torch.manual_seed(17)
+    x = ops.alloc_view(N, H, W, cin, 1, dtype, cuda)
+    x.interior().normal_()
+    w = torch.randn(cout, cin, k, k) * (2.0 / (cin * k * k)) ** 0.5
+    wp, bp = ops.pack_conv(w, torch.zeros(cout), dtype, cuda)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    gamma, beta = torch.rand(cout, device=cuda) + 0.5, torch.randn(cout, device=cuda)
+    res = []
+    for fused in (False, True):
+        z = ops.alloc_view(N, Ho, Wo, cout, 0, dtype, cuda)
+        stats = torch.zeros(5, cout, device=cuda)
+        rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+        if fused:
+            sums = torch.full((ops.lib().yolo_conv2d_bnsums_rows(N * Ho * Wo, cout) * 2 * cout,), float("nan"), device=cuda)
+            rows = ops.conv2d_fwd_bnsums(x, wp, bp, z, sums, cin=cin, cout=cout, k=k, stride=s)
+            ops.bn_train_finalize(sums, rows, N * Ho * Wo, gamma, beta, stats, eps=1e-5, momentum=0.1,
+                                  running_mean=rm, running_var=rv)
+        else:
+            ops.conv2d_fwd(x, wp, bp, z, cin=cin, cout=cout, k=k, stride=s, slope=1.0)
+            ws = torch.empty(ops.bn_workspace_bytes(N, Ho, Wo, cout), dtype=torch.uint8, device=cuda)
+            ops.bn_train_stats(z, gamma, beta, stats, ws, eps=1e-5, momentum=0.1, running_mean=rm, running_var=rv)
+        torch.cuda.synchronize()
+        res.append((z.buf.clone(), stats, rm, rv))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.isfinite(b).all() and _rel(b, a) < 2e-5

@@ -42,6 +42,7 @@ struct ConvParams {
     float slope;
     int upsample;
     int y_f32;  // output element type is f32 (else bf16)
+    float* stats;  // STATS kernels: per pixel tile, per channel: [n_ptiles][2][Cout] sums of y and y*y
 };
 
 constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
@@ -53,7 +54,9 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 
 // T: element type of x / w / residual.  TC x TP: channel x pixel tile of one workgroup (4 waves laid
 // out WC x WP).  TAP2: bf16 with Cin == 32, one k-step spans two filter taps.
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4>
+// STATS: additionally leave, per pixel tile, the per-channel sums of the output values as stored (after rounding
+// to the output type) and of their squares -- the first pass of a training-mode BatchNorm over this output.
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false>
 __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p) {
     static_assert(WC * WP == NW, "waves");
     constexpr bool BF = sizeof(T) == 2;
@@ -227,6 +230,11 @@ __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p)
     constexpr int PPP = NW * 64 / G;  // pixels per pass
     const int g = tid % G;
     const int ch_first = tile_c * TC + g * 8;
+    float st_s[8], st_q[8];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
+    }
     if (ch_first < p.Cout) {
 #pragma unroll 1
         for (int pass = 0; pass < TP / PPP; ++pass) {
@@ -277,15 +285,56 @@ __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p)
                         *(u32x4*)o = packed;
                     }
                 }
+            if constexpr (STATS) {
+                float z[8];
+                if (p.y_f32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        z[e] = v0[e];
+                        z[4 + e] = v1[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        z[2 * e] = __uint_as_float(packed[e] << 16);
+                        z[2 * e + 1] = __uint_as_float(packed[e] & 0xffff0000u);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    st_s[e] += z[e];
+                    st_q[e] += z[e] * z[e];
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // fold the pixel lanes of the workgroup: [which][pixel lane][channel] through LDS (the staged tile is done)
+        constexpr int PL = NW * 64 / G;
+        float* red = (float*)smem;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(tid / G) * TC + g * 8 + e] = st_s[e];
+            red[(PL + tid / G) * TC + g * 8 + e] = st_q[e];
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * TC; t += NW * 64) {
+            const int which = t / TC, c = t - which * TC;
+            float a = 0.f;
+#pragma unroll 4
+            for (int l = 0; l < PL; ++l) a += red[(which * PL + l) * TC + c];
+            const int cg = tile_c * TC + c;
+            if (cg < p.Cout) p.stats[((long long)tile_p * 2 + which) * p.Cout + cg] = a;
         }
     }
 }
 
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4>
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // two operand buffers, or the f32 epilogue staging tile if that is larger
     constexpr int LDS = 2 * (TC + TP) * ROWB > TP * TC * 4 ? 2 * (TC + TP) * ROWB : TP * TC * 4;
-    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW>;
+    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS>;
     static bool attr_set = false;
     if (!attr_set) {
         YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -313,6 +362,17 @@ static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream) {
     p.n_ctiles = (p.Cout + tc - 1) / tc;
     const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles) : 128;
     p.n_ptiles = (p.M + tp - 1) / tp;
+    if constexpr (!TAP2) {
+        if (p.stats) {
+            switch (tc) {
+                case 128:
+                    if (tp == 96) return launch_conv<T, 128, 96, 2, 2, false, 4, true>(p, stream);
+                    return launch_conv<T, 128, 128, 2, 2, false, 4, true>(p, stream);
+                case 64: return launch_conv<T, 64, 128, 2, 2, false, 4, true>(p, stream);
+                default: YOLO_REQUIRE(false, "conv2d with BatchNorm sums: Cout %d (needs > 32)", p.Cout);
+            }
+        }
+    }
     switch (tc) {
         case 128:
             if (tp == 96) return launch_conv<T, 128, 96, 2, 2, TAP2>(p, stream);
@@ -336,9 +396,12 @@ extern "C" int yolo_conv_tile_shape(int M, int Cout, int* tile_channels, int* ti
     return YOLO_OK;
 }
 
-extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,
-                               const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
-                               int stride, float leaky_slope, int upsample2x, int dtype, int y_dtype, void* stream) {
+
+static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* residual,
+                       const yolo_view* y, int N, int Cin, int Cout, int k, int stride, float leaky_slope, int upsample2x,
+                       int dtype, int y_dtype, float* stats, size_t stats_bytes, void* stream) {
     YOLO_REQUIRE(x && y && w_packed && bias, "conv2d: null argument");
     YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "conv2d: dtype %d", dtype);
     YOLO_REQUIRE(y_dtype == YOLO_F32 || y_dtype == YOLO_BF16, "conv2d: y_dtype %d", y_dtype);
@@ -413,8 +476,37 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
     p.upsample = upsample2x ? 1 : 0;
     p.y_f32 = y_dtype == YOLO_F32;
 
-    const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);  // keep in step with yolo_conv_tile_shape
+    const int tc = conv_tc(Cout);
+    if (stats) {
+        YOLO_REQUIRE(!tap2 && !upsample2x && !residual, "conv2d with BatchNorm sums: plain convolutions only");
+        const int tp = tc == 128 ? pick_tp(p.M, (Cout + tc - 1) / tc) : 128;
+        YOLO_REQUIRE(stats_bytes >= (size_t)((p.M + tp - 1) / tp) * 2 * Cout * sizeof(float),
+                     "conv2d with BatchNorm sums: buffer of %zu bytes is too small", stats_bytes);
+        p.stats = stats;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == YOLO_BF16) return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st);
     return dispatch_tc<float, false>(p, tc, st);
+}
+
+extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,
+                               const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
+                               int stride, float leaky_slope, int upsample2x, int dtype, int y_dtype, void* stream) {
+    return conv2d_impl(x, w_packed, bias, residual, y, N, Cin, Cout, k, stride, leaky_slope, upsample2x, dtype, y_dtype,
+                       nullptr, 0, stream);
+}
+
+extern "C" int yolo_conv2d_bnsums_rows(int M, int Cout) {
+    if (M <= 0 || Cout <= 0) return 0;
+    const int tc = conv_tc(Cout);
+    const int tp = tc == 128 ? pick_tp(M, (Cout + tc - 1) / tc) : 128;
+    return (M + tp - 1) / tp;
+}
+
+extern "C" int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* y,
+                                      int N, int Cin, int Cout, int k, int stride, int dtype, float* sums,
+                                      size_t sums_bytes, void* stream) {
+    YOLO_REQUIRE(sums, "conv2d_fwd_bnsums: null argument");
+    return conv2d_impl(x, w_packed, bias, nullptr, y, N, Cin, Cout, k, stride, 1.0f, 0, dtype, dtype, sums, sums_bytes,
+                       stream);
 }

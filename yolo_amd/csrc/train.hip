@@ -417,6 +417,32 @@ extern "C" int yolo_bn_train_stats(const yolo_view* z, int N, int C, int dtype, 
     return YOLO_OK;
 }
 
+extern "C" int yolo_bn_train_finalize(const float* sums, int rows, long long count, int C, const float* gamma,
+                                      const float* beta, float eps, float momentum, float* running_mean,
+                                      float* running_var, float* stats, void* stream) {
+    YOLO_REQUIRE(sums && gamma && beta && stats && rows > 0 && count > 0 && C > 0, "bn_train_finalize: bad argument");
+    YOLO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_finalize: running stats come in pairs");
+    FinParams f{};
+    f.partial = sums;
+    f.blocks = rows;
+    f.C = C;
+    f.count = (double)count;
+    f.gamma = gamma;
+    f.beta = beta;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean = stats;
+    f.var = stats + C;
+    f.invstd = stats + 2 * C;
+    f.scale = stats + 3 * C;
+    f.shift = stats + 4 * C;
+    f.running_mean = running_mean;
+    f.running_var = running_var;
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, f);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
 static void fill_apply(ApplyParams& p, const yolo_view* z, const yolo_view* r, const yolo_view* y, int N, int C, int es) {
     const ViewGeom gz = geom_of(*z), gy = geom_of(*y);
     p.z = (const char*)z->ptr;

@@ -521,3 +521,27 @@ def train_loss_bwd(ctx: LossContext, dheads: Sequence[View], grad_losses: torch.
                                     _ptr(ctx.gt_boxes), _ptr(ctx.gt_classes), _ptr(ctx.gt_count), K, ctx.obj_weight,
                                     ctx.noobj_weight, _ptr(grad_losses.contiguous()), _ptr(ctx.ws), ctx.ws.numel(),
                                     _stream()), "yolo_train_loss_bwd")
+
+
+def conv2d_fwd_bnsums(x: View, w_packed: torch.Tensor, bias: torch.Tensor, z: View, sums: torch.Tensor, *, cin: int,
+                      cout: int, k: int, stride: int) -> int:
+    """z = conv(x) (linear) and, from the same launch, the per-pixel-tile sums of z and z*z that a training-mode
+    BatchNorm needs.  Returns the number of rows written to ``sums`` ([rows, 2, cout] f32)."""
+    _require_cuda(x.buf, "conv2d_fwd_bnsums")
+    assert sums.dtype == torch.float32 and sums.is_contiguous() and z.buf.dtype == x.buf.dtype
+    rows = lib().yolo_conv2d_bnsums_rows(x.N * z.H * z.W, cout)
+    xv, zv = x.c(), z.c()
+    check(lib().yolo_conv2d_fwd_bnsums(ctypes.byref(xv), _ptr(w_packed), _ptr(bias), ctypes.byref(zv), x.N, cin, cout, k,
+                                       stride, dtype_code(x.buf.dtype), _ptr(sums), sums.numel() * 4, _stream()),
+          "yolo_conv2d_fwd_bnsums")
+    return rows
+
+
+def bn_train_finalize(sums: torch.Tensor, rows: int, count: int, gamma: torch.Tensor, beta: torch.Tensor,
+                      stats: torch.Tensor, *, eps: float, momentum: float, running_mean=None, running_var=None) -> None:
+    """Per-tile sums -> stats [5, C] (mean, biased var, invstd, scale, shift) + running-statistics update."""
+    C = gamma.numel()
+    assert stats.dtype == torch.float32 and stats.numel() >= 5 * C and stats.is_contiguous()
+    check(lib().yolo_bn_train_finalize(_ptr(sums), rows, count, C, _ptr(gamma), _ptr(beta), eps, momentum,
+                                       _ptr(running_mean), _ptr(running_var), _ptr(stats), _stream()),
+          "yolo_bn_train_finalize")

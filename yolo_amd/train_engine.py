@@ -27,6 +27,7 @@ optimizer's multi-tensor kernels see matching strides, and data-parallel trainin
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -78,6 +79,7 @@ class TPlan:
     stem_y: Optional[View] = None
     stem_out: Optional[View] = None
     bn_ws: Optional[torch.Tensor] = None
+    bn_sums: Optional[torch.Tensor] = None  # per-tile BatchNorm sums written by the conv epilogue
     wg_ws: Optional[torch.Tensor] = None
     arena: Optional[torch.Tensor] = None   # all parameter gradients, flat fp32, in backward order
     bucketer: Optional[object] = None
@@ -113,6 +115,7 @@ class TrainEngine:
         self._zero_bias: Dict[int, torch.Tensor] = {}
         self.bucket_bytes = 64 << 20
         self.process_group = None
+        self.fuse_bn_sums = os.environ.get("YOLO_FUSE_BN_SUMS", "1") != "0"
         self.param_arena: Optional[torch.Tensor] = None
         self.grad_arena: Optional[torch.Tensor] = None
         self._adopted: List[Tuple[torch.nn.Parameter, torch.Tensor, torch.Tensor]] = []  # (param, data view, grad view)
@@ -374,6 +377,9 @@ class TrainEngine:
             L.arena_end = end
         n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
         P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
+        n_sums = max(ops.lib().yolo_conv2d_bnsums_rows(N * L.y.H * L.y.W, L.conv.out_channels) * 2 * L.conv.out_channels
+                     for L in P.layers if L.z is not None)
+        P.bn_sums = torch.empty(n_sums, device=dev)
         n_wg = max(ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
                                              L.conv.kernel_size) for L in P.layers if not L.frozen)
         P.wg_ws = torch.empty(n_wg, dtype=torch.uint8, device=dev)
@@ -415,11 +421,18 @@ class TrainEngine:
                 ops.conv2d_fwd(L.x, w, b, L.y, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride,
                                slope=1.0)
                 continue
-            ops.conv2d_fwd(L.x, w, b, L.z, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride, slope=1.0)
             n = c.norm
-            ops.bn_train_stats(L.z, n.weight.detach(), n.bias.detach(), L.stats, P.bn_ws, eps=n.eps, momentum=BN_MOMENTUM,
-                               running_mean=n.running_mean if update_running_stats else None,
-                               running_var=n.running_var if update_running_stats else None)
+            rm, rv = (n.running_mean, n.running_var) if update_running_stats else (None, None)
+            if self.fuse_bn_sums:   # the conv epilogue leaves per-tile sums of z and z*z: no second pass over z
+                rows = ops.conv2d_fwd_bnsums(L.x, w, b, L.z, P.bn_sums, cin=c.in_channels, cout=c.out_channels,
+                                             k=c.kernel_size, stride=c.stride)
+                ops.bn_train_finalize(P.bn_sums, rows, N * L.z.H * L.z.W, n.weight.detach(), n.bias.detach(), L.stats,
+                                      eps=n.eps, momentum=BN_MOMENTUM, running_mean=rm, running_var=rv)
+            else:
+                ops.conv2d_fwd(L.x, w, b, L.z, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride,
+                               slope=1.0)
+                ops.bn_train_stats(L.z, n.weight.detach(), n.bias.detach(), L.stats, P.bn_ws, eps=n.eps,
+                                   momentum=BN_MOMENTUM, running_mean=rm, running_var=rv)
             ops.bn_act_fwd(L.z, L.stats, L.y, slope=L.slope, residual=L.residual)
             if L.up_dst is not None:
                 ops.upsample2x(L.y, L.up_dst)
