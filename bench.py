@@ -56,13 +56,13 @@ def _barrier(world: int):
 
 
 def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int = 3):
-    """The dominant kernel is the 128-channel x 128-pixel bf16 implicit-GEMM instance
-    (conv_igemm_kernel<bf16,128,128,2,2,false>; yolo_conv_tile_shape says which launches use it).  Its launches
-    are timed where they run: the whole plan is replayed in order with a HIP event pair (on the launch stream)
-    around each of them, so every launch sees the cache state it sees in a real step; the cost of an empty event
-    pair is measured the same way and subtracted.  achieved = algorithmic FLOPs (2 * pixels * Cout * Cin * k * k
-    per launch) / time.  The 128x96 instance of the same kernel, used where it quantises better over the 512
-    resident workgroups, is reported next to it."""
+    """The convolutions run as instances of one implicit-GEMM kernel that differ in their workgroup tile
+    (conv_igemm_kernel<bf16, channels, pixels, ...>; yolo_conv_tile_shape says which launch uses which).  Every
+    launch of the 128-channel instances is timed where it runs: the whole plan is replayed in order with a HIP event
+    pair (on the launch stream) around each of them, so every launch sees the cache state it sees in a real step;
+    the cost of an empty event pair is measured the same way and subtracted.  The instance with the most time is
+    the dominant kernel: achieved = its algorithmic FLOPs (2 * pixels * Cout * Cin * k * k per launch) / its time.
+    The other instances are reported next to it."""
     from yolo_amd import ops
     stream = torch.cuda.current_stream()
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -73,7 +73,7 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
             continue
         up = 2 if meta["up"] else 1
         M = plan.N * (meta["y"].H // up) * (meta["y"].W // up)
-        tc, tp = ops.conv_tile_shape(M, c.out_channels)
+        tc, tp = ops.conv_tile_shape(M, c.in_channels, c.out_channels, c.kernel_size, meta["x"].buf.dtype)
         if tc != 128:
             continue
         es = meta["x"].buf.element_size()
@@ -103,29 +103,32 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
         empty += e0.elapsed_time(e1) / passes
         for k, (a, b) in enumerate(pairs):
             ms[k] += a.elapsed_time(b) / passes
-    acc = {128: [0.0, 0.0, 0, 0.0], 96: [0.0, 0.0, 0, 0.0]}
+    acc = {}
     for (i, tp, fl, by), t in zip(timed, ms):
-        acc[tp][0] += fl
-        acc[tp][1] += max(t - empty, 1e-6)
-        acc[tp][2] += 1
-        acc[tp][3] += by
-    flops, t128, launches, by128 = acc[128]
-    achieved = flops / (t128 * 1e-3) / 1e12
+        a = acc.setdefault(tp, [0.0, 0.0, 0, 0.0])
+        a[0] += fl
+        a[1] += max(t - empty, 1e-6)
+        a[2] += 1
+        a[3] += by
+    dom = max(acc, key=lambda tp: acc[tp][1])
+    flops, t_ms, launches, by = acc[dom]
+    achieved = flops / (t_ms * 1e-3) / 1e12
     out = dict(bound="mfma", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
-               kernel="conv_igemm_kernel<bf16,128,128,2,2,false>", launches_per_step=launches,
-               avg_launch_us=round(t128 * 1e3 / launches, 2), flop_per_launch=round(flops / launches / 1e9, 3),
-               algorithmic_bytes_per_launch=round(by128 / launches), event_pair_overhead_us=round(empty * 1e3, 2))
+               kernel=f"conv_igemm_kernel<bf16,128,{dom},2,2,false>", launches_per_step=launches,
+               avg_launch_us=round(t_ms * 1e3 / launches, 2), flop_per_launch=round(flops / launches / 1e9, 3),
+               algorithmic_bytes_per_launch=round(by / launches), event_pair_overhead_us=round(empty * 1e3, 2))
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
         with open(pmc) as f:
             rec = json.load(f)
-        out["traffic"] = rec.get("hbm_bytes_per_launch")
-        out["traffic_source"] = rec.get("source")
-    if acc[96][2]:
-        f2, m2, l2, _ = acc[96]
-        out["tile_128x96_instance"] = dict(achieved=round(f2 / (m2 * 1e-3) / 1e12, 1), launches_per_step=l2,
-                                           avg_launch_us=round(m2 * 1e3 / l2, 2))
+        if rec.get("kernel", out["kernel"]) == out["kernel"]:
+            out["traffic"] = rec.get("hbm_bytes_per_launch")
+            out["traffic_source"] = rec.get("source")
+    out["other_instances"] = {
+        f"128x{tp}": dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
+                          avg_launch_us=round(a[1] * 1e3 / a[2], 2))
+        for tp, a in sorted(acc.items()) if tp != dom}
     return out
 
 

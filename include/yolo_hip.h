@@ -81,7 +81,7 @@ int yolo_conv_cout_pad(int Cout);
 
 /* Introspection for benchmarks and profilers: the workgroup tile (output channels x output pixels) that
  * yolo_conv2d_fwd uses for M = N*Ho*Wo output pixels and Cout channels, i.e. which kernel instance runs. */
-int yolo_conv_tile_shape(int M, int Cout, int* tile_channels, int* tile_pixels);
+int yolo_conv_tile_shape(int M, int Cin, int Cout, int k, int dtype, int* tile_channels, int* tile_pixels);
 
 /*
  * Alternative kernel for the 3x3 / stride-1 / bf16 case of yolo_conv2d_fwd (same reference call sites,
@@ -230,7 +230,7 @@ size_t yolo_bn_workspace_bytes(int N, int H, int W, int C);
 /*
  * The same convolution as yolo_conv2d_fwd (linear, no residual, output type = operand type) that also leaves
  * the first pass of the following training-mode BatchNorm (detectron2 Conv2d.forward: F.conv2d, then self.norm):
- *   sums  [rows][2][Cout] f32, rows = yolo_conv2d_bnsums_rows(N*Ho*Wo, Cout): per pixel tile and channel, the sum
+ *   sums  [rows][2][Cout] f32, rows = yolo_conv2d_bnsums_rows(N*Ho*Wo, Cin, Cout, k, dtype): per pixel tile and channel, the sum
  *         of the output values as stored and of their squares
  * yolo_bn_train_finalize turns the rows into what yolo_bn_train_stats writes (stats [5][C], running statistics);
  * count = N*Ho*Wo.  Together they replace yolo_conv2d_fwd + yolo_bn_train_stats without re-reading z.
@@ -238,7 +238,7 @@ size_t yolo_bn_workspace_bytes(int N, int H, int W, int C);
 int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* y,
                            int N, int Cin, int Cout, int k, int stride, int dtype, float* sums,
                            size_t sums_bytes, void* stream);
-int yolo_conv2d_bnsums_rows(int M, int Cout);
+int yolo_conv2d_bnsums_rows(int M, int Cin, int Cout, int k, int dtype);
 int yolo_bn_train_finalize(const float* sums, int rows, long long count, int C, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, float* stats, void* stream);

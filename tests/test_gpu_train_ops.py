@@ -208,7 +208,7 @@ def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
         stats = torch.zeros(5, cout, device=cuda)
         rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
         if fused:
-            sums = torch.full((ops.lib().yolo_conv2d_bnsums_rows(N * Ho * Wo, cout) * 2 * cout,), float("nan"), device=cuda)
+            sums = torch.full((ops.conv_bnsums_rows(N * Ho * Wo, cin, cout, k, dtype) * 2 * cout,), float("nan"), device=cuda)
             rows = ops.conv2d_fwd_bnsums(x, wp, bp, z, sums, cin=cin, cout=cout, k=k, stride=s)
             ops.bn_train_finalize(sums, rows, N * Ho * Wo, gamma, beta, stats, eps=1e-5, momentum=0.1,
                                   running_mean=rm, running_var=rv)

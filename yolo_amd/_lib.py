@@ -30,7 +30,7 @@ SIGNATURES = {
     "yolo_last_error": (ctypes.c_char_p, []),
     "yolo_abi_version": (c_int, []),
     "yolo_conv_cout_pad": (c_int, [c_int]),
-    "yolo_conv_tile_shape": (c_int, [c_int, c_int, _IP, _IP]),
+    "yolo_conv_tile_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, _IP, _IP]),
     "yolo_conv3x3_patch_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_float, c_void_p]),
     "yolo_conv2d_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_int, c_int, c_void_p]),
@@ -57,7 +57,7 @@ SIGNATURES = {
                                     c_void_p]),
     "yolo_conv2d_fwd_bnsums": (c_int, [_VP, c_void_p, c_void_p, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_size_t, c_void_p]),
-    "yolo_conv2d_bnsums_rows": (c_int, [c_int, c_int]),
+    "yolo_conv2d_bnsums_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "yolo_bn_train_finalize": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_float, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "yolo_pack_conv_train_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -57,7 +57,7 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // STATS: additionally leave, per pixel tile, the per-channel sums of the output values as stored (after rounding
 // to the output type) and of their squares -- the first pass of a training-mode BatchNorm over this output.
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false>
-__global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(const ConvParams p) {
     static_assert(WC * WP == NW, "waves");
     constexpr bool BF = sizeof(T) == 2;
     constexpr int W_BYTES = TC * ROWB, X_BYTES = TP * ROWB, BUF = W_BYTES + X_BYTES;
@@ -205,13 +205,29 @@ __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p)
         if (s + 1 < p.nsteps) stage(smem + ((s + 1) & 1) * BUF);
         compute(smem + (s & 1) * BUF);
     }
+    // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte chunks XOR-swizzled by
+    //      (pixel & 7); epilogue 2: one lane = 8 channels of one pixel, whole pixel rows leave as contiguous bytes.
+    //      A tile whose f32 image would not fit the operand buffers goes through in two pixel halves (the
+    //      halves of the 2-wide pixel wave grid).
+    constexpr int NH = TP * TC * 4 > 2 * BUF ? 2 : 1;
+    constexpr int HP = TP / NH;
+    static_assert(NH == 1 || WP == 2, "halves follow the pixel wave grid");
+    constexpr int G = TC / 8;       // 8-channel groups per pixel
+    constexpr int PPP = NW * 64 / G;  // pixels per pass
+    static_assert(HP % PPP == 0, "whole passes");
+    const int g = tid % G;
+    const int ch_first = tile_c * TC + g * 8;
+    float st_s[8], st_q[8];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
+    }
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
     __syncthreads();
-
-    // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte
-    //      chunks XOR-swizzled by (pixel & 7)
-    {
+    if (NH == 1 || wp == half) {
         const int ch0 = wc * (TC / WC) + q * 4;
-        const int px0 = wp * (TP / WP) + l15;
+        const int px0 = (NH == 1 ? wp * (TP / WP) : 0) + l15;
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             const int ch = ch0 + i * 16;
@@ -224,22 +240,11 @@ __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p)
         }
     }
     __syncthreads();
-
-    // ---- epilogue 2: one lane = 8 channels of one pixel; whole pixel rows leave as contiguous bytes
-    constexpr int G = TC / 8;       // 8-channel groups per pixel
-    constexpr int PPP = NW * 64 / G;  // pixels per pass
-    const int g = tid % G;
-    const int ch_first = tile_c * TC + g * 8;
-    float st_s[8], st_q[8];
-    if constexpr (STATS) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
-    }
     if (ch_first < p.Cout) {
 #pragma unroll 1
-        for (int pass = 0; pass < TP / PPP; ++pass) {
+        for (int pass = 0; pass < HP / PPP; ++pass) {
             const int px = pass * PPP + tid / G;
-            const int m = tile_p * TP + px;
+            const int m = tile_p * TP + half * HP + px;
             if (m >= p.M) break;
             const int n = m / HoWo;
             const int rem = m - n * HoWo;
@@ -308,6 +313,7 @@ __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p)
             }
         }
     }
+    }  // half
     if constexpr (STATS) {
         // fold the pixel lanes of the workgroup: [which][pixel lane][channel] through LDS (the staged tile is done)
         constexpr int PL = NW * 64 / G;
@@ -333,7 +339,8 @@ __global__ void __launch_bounds__(NW * 64) conv_igemm_kernel(const ConvParams p)
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // two operand buffers, or the f32 epilogue staging tile if that is larger
-    constexpr int LDS = 2 * (TC + TP) * ROWB > TP * TC * 4 ? 2 * (TC + TP) * ROWB : TP * TC * 4;
+    constexpr int OPS = 2 * (TC + TP) * ROWB, STG = TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4;
+    constexpr int LDS = OPS > STG ? OPS : STG;
     auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -346,27 +353,52 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     return YOLO_OK;
 }
 
-// Pixel-tile choice: two workgroups share a CU, so a launch runs in rounds of 512 tiles; pick the pixel
-// tile (96 or 128) that needs the least total tile-time (rounds x pixels per tile).
-static int pick_tp(int M, int n_ctiles) {
+// Pixel-tile choice: two workgroups share a CU, so a launch runs in rounds of 512 tiles; pick the pixel tile with
+// the least total tile-time (rounds x pixels per tile x relative cost per pixel).  The 192-pixel tile moves 17 %
+// fewer operand bytes per FLOP than 128 x 128 (measured 5-12 % faster per pixel on long-K layers) but pays its
+// two-half epilogue and longer prologue on short ones: only from 18 k-steps up.
+static int pick_tp(int M, int n_ctiles, int nsteps) {
+    static const int force = getenv("YOLO_TP") ? atoi(getenv("YOLO_TP")) : 0;
+    if (force == 96 || force == 128 || force == 192) return force;
     const long long slots = 512;
-    auto cost = [&](int tp) {
+    auto cost = [&](int tp, long long per_pixel) {
         const long long tiles = (long long)((M + tp - 1) / tp) * n_ctiles;
-        return ((tiles + slots - 1) / slots) * tp;
+        return ((tiles + slots - 1) / slots) * tp * per_pixel;
     };
-    return cost(96) < cost(128) ? 96 : 128;
+    int best = 128;
+    long long c = cost(128, 100);
+    if (cost(96, 100) < c) {
+        best = 96;
+        c = cost(96, 100);
+    }
+    if (nsteps >= 18 && cost(192, 92) < c) best = 192;
+    return best;
+}
+
+static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+static int conv_nsteps(int Cin, int k, int dtype) {
+    if (dtype == YOLO_BF16 && Cin == 32 && k == 3) return 5;
+    return k * k * (Cin / (ROWB / (int)elem_size(dtype)));
+}
+
+// channel x pixel tile of a convolution with M output pixels
+static void conv_tile(int M, int Cin, int Cout, int k, int dtype, int* tc, int* tp) {
+    *tc = conv_tc(Cout);
+    *tp = *tc == 128 ? pick_tp(M, (Cout + *tc - 1) / *tc, conv_nsteps(Cin, k, dtype)) : 128;
 }
 
 template <typename T, bool TAP2>
 static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream) {
     p.n_ctiles = (p.Cout + tc - 1) / tc;
-    const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles) : 128;
+    const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles, p.nsteps) : 128;
     p.n_ptiles = (p.M + tp - 1) / tp;
     if constexpr (!TAP2) {
         if (p.stats) {
             switch (tc) {
                 case 128:
                     if (tp == 96) return launch_conv<T, 128, 96, 2, 2, false, 4, true>(p, stream);
+                    if (tp == 192) return launch_conv<T, 128, 192, 2, 2, false, 4, true>(p, stream);
                     return launch_conv<T, 128, 128, 2, 2, false, 4, true>(p, stream);
                 case 64: return launch_conv<T, 64, 128, 2, 2, false, 4, true>(p, stream);
                 default: YOLO_REQUIRE(false, "conv2d with BatchNorm sums: Cout %d (needs > 32)", p.Cout);
@@ -376,6 +408,7 @@ static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream) {
     switch (tc) {
         case 128:
             if (tp == 96) return launch_conv<T, 128, 96, 2, 2, TAP2>(p, stream);
+            if (tp == 192) return launch_conv<T, 128, 192, 2, 2, TAP2>(p, stream);
             return launch_conv<T, 128, 128, 2, 2, TAP2>(p, stream);
         case 64: return launch_conv<T, 64, 128, 2, 2, TAP2>(p, stream);
         default: return launch_conv<T, 32, 128, 1, 4, TAP2>(p, stream);
@@ -388,16 +421,12 @@ using namespace yolo;
 
 extern "C" int yolo_conv_cout_pad(int Cout) { return (Cout + 127) / 128 * 128; }
 
-extern "C" int yolo_conv_tile_shape(int M, int Cout, int* tile_channels, int* tile_pixels) {
-    YOLO_REQUIRE(M > 0 && Cout > 0 && tile_channels && tile_pixels, "conv_tile_shape: bad argument");
-    const int tc = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-    *tile_channels = tc;
-    *tile_pixels = tc == 128 ? pick_tp(M, (Cout + tc - 1) / tc) : 128;
+extern "C" int yolo_conv_tile_shape(int M, int Cin, int Cout, int k, int dtype, int* tile_channels, int* tile_pixels) {
+    YOLO_REQUIRE(M > 0 && Cin > 0 && Cout > 0 && tile_channels && tile_pixels, "conv_tile_shape: bad argument");
+    conv_tile(M, Cin, Cout, k, dtype, tile_channels, tile_pixels);
     return YOLO_OK;
 }
 
-
-static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
 static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* residual,
                        const yolo_view* y, int N, int Cin, int Cout, int k, int stride, float leaky_slope, int upsample2x,
@@ -479,7 +508,7 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
     const int tc = conv_tc(Cout);
     if (stats) {
         YOLO_REQUIRE(!tap2 && !upsample2x && !residual, "conv2d with BatchNorm sums: plain convolutions only");
-        const int tp = tc == 128 ? pick_tp(p.M, (Cout + tc - 1) / tc) : 128;
+        const int tp = tc == 128 ? pick_tp(p.M, (Cout + tc - 1) / tc, p.nsteps) : 128;
         YOLO_REQUIRE(stats_bytes >= (size_t)((p.M + tp - 1) / tp) * 2 * Cout * sizeof(float),
                      "conv2d with BatchNorm sums: buffer of %zu bytes is too small", stats_bytes);
         p.stats = stats;
@@ -496,10 +525,10 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
                        nullptr, 0, stream);
 }
 
-extern "C" int yolo_conv2d_bnsums_rows(int M, int Cout) {
-    if (M <= 0 || Cout <= 0) return 0;
-    const int tc = conv_tc(Cout);
-    const int tp = tc == 128 ? pick_tp(M, (Cout + tc - 1) / tc) : 128;
+extern "C" int yolo_conv2d_bnsums_rows(int M, int Cin, int Cout, int k, int dtype) {
+    if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    int tc, tp;
+    conv_tile(M, Cin, Cout, k, dtype, &tc, &tp);
     return (M + tp - 1) / tp;
 }
 

@@ -136,11 +136,18 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, devi
     return wp.contiguous(), bp
 
 
-def conv_tile_shape(M: int, cout: int) -> Tuple[int, int]:
-    """(channels, pixels) of the workgroup tile yolo_conv2d_fwd picks for M output pixels, cout channels."""
+def conv_tile_shape(M: int, cin: int, cout: int, k: int, dtype: torch.dtype = torch.bfloat16) -> Tuple[int, int]:
+    """(channels, pixels) of the workgroup tile yolo_conv2d_fwd picks for a cin -> cout, k x k convolution with M
+    output pixels."""
     tc, tp = ctypes.c_int(0), ctypes.c_int(0)
-    check(lib().yolo_conv_tile_shape(int(M), int(cout), ctypes.byref(tc), ctypes.byref(tp)), "yolo_conv_tile_shape")
+    check(lib().yolo_conv_tile_shape(int(M), int(cin), int(cout), int(k), dtype_code(dtype), ctypes.byref(tc),
+                                     ctypes.byref(tp)), "yolo_conv_tile_shape")
     return tc.value, tp.value
+
+
+def conv_bnsums_rows(M: int, cin: int, cout: int, k: int, dtype: torch.dtype) -> int:
+    """Rows of per-tile sums conv2d_fwd_bnsums writes for this convolution."""
+    return lib().yolo_conv2d_bnsums_rows(int(M), int(cin), int(cout), int(k), dtype_code(dtype))
 
 
 def pack_stem(weight: torch.Tensor, bias: torch.Tensor, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -529,7 +536,7 @@ def conv2d_fwd_bnsums(x: View, w_packed: torch.Tensor, bias: torch.Tensor, z: Vi
     BatchNorm needs.  Returns the number of rows written to ``sums`` ([rows, 2, cout] f32)."""
     _require_cuda(x.buf, "conv2d_fwd_bnsums")
     assert sums.dtype == torch.float32 and sums.is_contiguous() and z.buf.dtype == x.buf.dtype
-    rows = lib().yolo_conv2d_bnsums_rows(x.N * z.H * z.W, cout)
+    rows = conv_bnsums_rows(x.N * z.H * z.W, cin, cout, k, x.buf.dtype)
     xv, zv = x.c(), z.c()
     check(lib().yolo_conv2d_fwd_bnsums(ctypes.byref(xv), _ptr(w_packed), _ptr(bias), ctypes.byref(zv), x.N, cin, cout, k,
                                        stride, dtype_code(x.buf.dtype), _ptr(sums), sums.numel() * 4, _stream()),

@@ -377,7 +377,8 @@ class TrainEngine:
             L.arena_end = end
         n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
         P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
-        n_sums = max(ops.lib().yolo_conv2d_bnsums_rows(N * L.y.H * L.y.W, L.conv.out_channels) * 2 * L.conv.out_channels
+        n_sums = max(ops.conv_bnsums_rows(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
+                                          L.conv.kernel_size, dt) * 2 * L.conv.out_channels
                      for L in P.layers if L.z is not None)
         P.bn_sums = torch.empty(n_sums, device=dev)
         n_wg = max(ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
