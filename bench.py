@@ -122,9 +122,10 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
         with open(pmc) as f:
             rec = json.load(f)
-        if rec.get("kernel", out["kernel"]) == out["kernel"]:
-            out["traffic"] = rec.get("hbm_bytes_per_launch")
-            out["traffic_source"] = rec.get("source")
+        hit = rec.get("kernels", {}).get(out["kernel"])
+        if hit:
+            out["traffic"] = hit["hbm_bytes_per_launch"]
+            out["traffic_source"] = "profiles/pmc_traffic.json: " + rec.get("source", "")
     out["other_instances"] = {
         f"128x{tp}": dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
                           avg_launch_us=round(a[1] * 1e3 / a[2], 2))

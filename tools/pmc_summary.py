@@ -1,0 +1,64 @@
+"""HBM-side traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command.
+
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+
+Counter unit: KiB.  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request of 16-byte-per-lane loads, so
+read bytes = 2 * FETCH_SIZE * 1024 (exact for the conv kernels' LDS-DMA loads); WRITE_SIZE is exact.  Infinity-
+Cache hits are counted, so this is traffic leaving L2: an upper bound on DRAM bytes.  Prints a table; the JSON
+(read by bench.py) holds the figures of the kernel named by --kernel-substring (default: the conv instance with
+the most launches x bytes)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    by_dispatch = defaultdict(float)
+    name_of = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            d = r["Dispatch_Id"]
+            by_dispatch[d] += float(r["Counter_Value"])
+            name_of[d] = r["Kernel_Name"]
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for d, v in by_dispatch.items():
+        tot[name_of[d]] += v
+        cnt[name_of[d]] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+def short(name):
+    m = re.search(r"conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d)ELi(\d)ELb(\d)", name)
+    if m:
+        return "conv_igemm_kernel<%s,%s,%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
+                                                        m.group(4), m.group(5), "true" if m.group(6) == "1" else "false")
+    return re.sub(r"^void |\(.*$", "", name).replace("yolo::", "")[:44]
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for k in fetch:
+        if k in write and ("yolo" in k):
+            f, n = fetch[k]
+            w, _ = write[k]
+            rows.append((short(k), n, f, w, (2 * f + w) * 1024))
+    rows.sort(key=lambda r: -r[1] * r[4])
+    print("%-46s %8s %15s %15s %18s" % ("kernel", "launches", "FETCH_SIZE KiB", "WRITE_SIZE KiB", "HBM bytes/launch"))
+    for r in rows:
+        print("%-46s %8d %15.1f %15.1f %18d" % r)
+    if len(sys.argv) > 3:
+        convs = [r for r in rows if r[0].startswith("conv_igemm_kernel<bf16,128")]
+        recs = {r[0]: dict(kernel=r[0], hbm_bytes_per_launch=round(r[4]), launches_sampled=r[1],
+                           fetch_size_kib_per_launch=round(r[2], 1), write_size_kib_per_launch=round(r[3], 1)) for r in convs}
+        with open(sys.argv[3], "w") as f:
+            json.dump(dict(kernels=recs, source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py; "
+                                                "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
