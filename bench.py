@@ -155,7 +155,7 @@ def _cpu_baseline(model, cfg, n_images: int = 8, reps: int = 2):
 
 
 def _train_throughput(steps: int = 4, warmup: int = 2, batch: int = 64):
-    """Secondary metric of the same hot path (BASELINE: "train img/s"): forward + backward + SGD step of
+    """Secondary metric of the same hot path (training images per second): forward + backward + SGD step of
     configs/yolov3.yaml at 416x416, batch 64, bf16, synthetic COCO-shaped targets, on this one GPU."""
     import workload
     from yolo_amd.trainer import Trainer, synthetic_batches
