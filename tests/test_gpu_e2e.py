@@ -183,3 +183,50 @@ def test_pipelined_detect_equals_detect(cuda, calibrated):
             assert torch.equal(d0[i, :k], d1[i, :k])
     assert total > 0
     model.backbone.compute_dtype = torch.float32
+
+
+def test_benchmark_size_properties(cuda):
+    """The benchmark's own configuration (batch 64, 416 x 416, bf16, 80 classes) is too large for the CPU oracle
+    in a test; checked through properties that do not depend on size: the result of an image does not depend on
+    its position in the batch or on its neighbours (bit-exact under a batch permutation and against batch 8),
+    repeated runs are identical, per-image scores are descending and above the threshold, at most 100
+    detections, boxes inside the frame with positive area, and NMS of the kept boxes of one class keeps them
+    all (idempotence, checked with the oracle's C NMS)."""
+    from oracle import nms_c
+    model, cfg = workload.calibrated_model(size=416, calib_batch=4, config="yolov3-aug.yaml", dtype="bf16", head_dtype="f32")
+    eng = model.backbone.engine()
+    kw = dict(score_thr=cfg.MODEL.YOLOV3.TEST_SCORE_THRESH, nms_thr=cfg.MODEL.YOLOV3.TEST_NMS_THRESH,
+              mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD)
+    imgs = workload.synthetic_images(64, 416, 416, seed=1, device="cuda")
+    det, n = (t.clone() for t in eng.detect(imgs, **kw))
+    det2, n2 = (t.clone() for t in eng.detect(imgs, **kw))
+    assert torch.equal(n, n2) and torch.equal(det, det2)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(5)).to("cuda")
+    detp, np_ = (t.clone() for t in eng.detect(imgs[perm].contiguous(), **kw))
+    assert torch.equal(np_, n[perm])
+    det8, n8 = (t.clone() for t in eng.detect(imgs[:8].contiguous(), **kw))
+    assert torch.equal(n8, n[:8])
+    assert int(n.sum()) > 1000 and int(n.max()) <= 100
+    for i in range(64):
+        k = int(n[i])
+        d = det[i, :k]
+        assert torch.equal(detp[(perm == i).nonzero()[0, 0], :k], d)
+        if i < 8:
+            assert torch.equal(det8[i, :k], d)
+        s = d[:, 4]
+        assert bool((s[:-1] >= s[1:]).all()) and float(s.min()) > kw["score_thr"] if k else True
+        assert bool((d[:, 0] >= 0).all() and (d[:, 1] >= 0).all() and (d[:, 2] <= 416).all() and (d[:, 3] <= 416).all())
+        assert bool(((d[:, 2] - d[:, 0]) > 0).all() and ((d[:, 3] - d[:, 1]) > 0).all())
+    # idempotence on a few images.  Clipping to the frame (after NMS, as in the reference) can raise IoUs, so only
+    # detections that were not clipped take part.
+    checked = 0
+    for i in range(0, 64, 8):
+        d = det[i, :int(n[i])].cpu()
+        inside = (d[:, 0] > 0) & (d[:, 1] > 0) & (d[:, 2] < 416) & (d[:, 3] < 416)
+        d = d[inside]
+        if len(d) < 2:
+            continue
+        keep = nms_c.batched_nms_vanilla(d[:, :4].contiguous(), d[:, 4].contiguous(), d[:, 5].long(), kw["nms_thr"])
+        assert len(keep) == len(d)
+        checked += 1
+    assert checked >= 4
