@@ -356,3 +356,45 @@ def test_fused_loss_kernels_match_the_oracle_golden(cuda):
     for i, d in enumerate(dheads):
         ref = torch.from_numpy(g[f"dhead{i}"]).permute(0, 2, 3, 1)
         assert float((d.interior()[..., :ak].cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_training_step_with_deeper_freeze_matches_oracle(cuda):
+    """MODEL.BACKBONE.FREEZE_AT = 3 (stem, res1 and res2 frozen: the frozen stage beyond the fused prefix runs as
+    folded inference convolutions inside the training plan): losses and gradients against the oracle, and no
+    gradient, no running-statistics update in the frozen stages."""
+    from oracle import yolo_train_ref as T
+    from yolo_amd.structures import Boxes, Instances
+    model, cfg = workload.build_model(config="yolov3.yaml", dtype="f32", opts=["MODEL.BACKBONE.FREEZE_AT", 3])
+    C, N, S = cfg.MODEL.YOLOV3.NUM_CLASSES, 2, 96
+    imgs = workload.synthetic_images(N, S, S, seed=5)
+    gb, gc = T.synthetic_targets(N, S, C, seed=13, max_boxes=5)
+    inputs = [dict(image=im, instances=Instances((S, S), gt_boxes=Boxes(b), gt_classes=c)) for im, b, c in zip(imgs, gb, gc)]
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    full = dict(sd)
+    full.update(params)
+    want = T.forward_training(imgs.float() / 255.0, full, gb, gc, C, freeze_at=3)
+    sum(want.values()).backward()
+    model.train()
+    got = model(inputs)
+    sum(got.values()).backward()
+    torch.cuda.synchronize()
+    for k in want:
+        assert abs(float(got[k].detach()) - float(want[k].detach())) / abs(float(want[k].detach())) < 1e-3, k
+    frozen = set(T.frozen_names(3))
+    assert any("res2" in f for f in frozen)
+    n = 0
+    for name, p in model.named_parameters():
+        layer = name.rsplit(".norm.", 1)[0].rsplit(".weight", 1)[0].rsplit(".bias", 1)[0]
+        if layer in frozen:
+            assert p.grad is None and not p.requires_grad, name
+            continue
+        g, ref = p.grad.float().cpu(), params[name].grad
+        assert float(F.cosine_similarity(g.flatten().double(), ref.flatten().double(), dim=0)) > 0.998, name
+        assert _l2(g, ref) < 0.06, (name, _l2(g, ref))
+        n += 1
+    assert 0 < n < 210
+    bufs = dict(model.named_buffers())
+    key = "backbone.bottom_up.res2.1.conv2.norm.running_var"
+    assert torch.equal(bufs[key].cpu(), sd[key])
+    model.eval()
