@@ -107,3 +107,33 @@ def test_grad_bucketer_single_process_is_a_noop():
     bk.ready(8)
     bk.finish()
     assert torch.equal(a, torch.ones(10)) and bk.launched == [(0, 4), (4, 8), (8, 10)]
+
+
+def _bcast_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from yolo_amd.utils import dist as D
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    ts = [torch.randn(3, 5), torch.randn(7).permute(0), torch.randint(0, 9, (4,)), torch.randn(2, 3, 4).permute(2, 0, 1)]
+    D.broadcast_tensors(ts, src=0)
+    q.put((rank, [t.clone().contiguous() for t in ts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_tensors_world2():
+    """Flat per-dtype broadcast: every rank ends with rank 0's values, also in non-contiguous tensors."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    torch.manual_seed(100)
+    want = [torch.randn(3, 5), torch.randn(7), torch.randint(0, 9, (4,)), torch.randn(2, 3, 4).permute(2, 0, 1)]
+    for a, b, w in zip(out[0], out[1], want):
+        assert torch.equal(a, b) and torch.equal(a, w.contiguous())

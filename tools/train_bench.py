@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     args = ap.parse_args()
+    if os.environ.get("YOLO_DEBUG_HANG"):   # dump every thread's stack and exit if the run takes this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["YOLO_DEBUG_HANG"]), exit=True)
     world, rank, local = D.init_from_env("nccl")
     torch.cuda.set_device(local if world > 1 else 0)
     model, cfg = workload.build_model(config=args.config, dtype="bf16", device=f"cuda:{torch.cuda.current_device()}",
@@ -43,6 +46,9 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, model.device)
+    # data-parallel invariant: after identical initial states and averaged gradients every rank holds the same weights
+    chk = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+    in_sync = D.max_over_ranks(chk) == -D.max_over_ranks(-chk)
     if rank == 0:
         eng = model.backbone.train_engine()
         fwd = 65.428e9 if cfg.MODEL.YOLOV3.NUM_CLASSES == 20 else 65.864e9
@@ -51,7 +57,7 @@ def main():
             "metric": "train images/sec (fwd + bwd + all-reduce + SGD)", "value": round(world * args.batch * args.steps / dt, 1),
             "n_gpus": world, "batch_per_gpu": args.batch, "size": args.size, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "conv_tflops": round(train_flop * world * args.batch * args.steps / dt / 1e12, 1),
-            "losses": {k: round(float(v), 4) for k, v in losses.items()}, "dtype": "bf16", "freeze_at": eng.freeze_at,
+            "losses": {k: round(float(v), 4) for k, v in losses.items()}, "dtype": "bf16", "freeze_at": eng.freeze_at, "params_in_sync": bool(in_sync),
             "config": args.config}))
     D.barrier()
 

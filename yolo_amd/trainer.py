@@ -53,8 +53,7 @@ class Trainer:
                                                optimizer=self.optimizer, scheduler=self.scheduler)
         self.iter = 0
         if self.world > 1:   # identical starting point on every rank
-            for t in list(model.parameters()) + list(model.buffers()):
-                torch.distributed.broadcast(t.data, src=0)
+            D.broadcast_tensors([t.data for t in list(model.parameters()) + list(model.buffers())], src=0)
 
     def resume_or_load(self, resume: bool = True) -> None:
         ck = self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)

@@ -20,6 +20,11 @@ def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # YOLO_DIST_BACKEND=gloo rehearses the multi-rank paths on a box with fewer GPUs than ranks (ranks then share
+    # cards and collectives go through the host); production runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("YOLO_DIST_BACKEND", backend)
+    if backend != "nccl" and torch.cuda.is_available():
+        local %= max(torch.cuda.device_count(), 1)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -42,7 +47,7 @@ def max_over_ranks(value: float, device="cpu") -> float:
     """MAX all-reduce of a scalar (the timed region of the slowest rank)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -66,6 +71,35 @@ def gather_counts(local_counts: torch.Tensor) -> List[torch.Tensor]:
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves GPU tensors through the host itself, slowly and (on this stack) not reliably; when a GPU tensor
+    meets the gloo backend -- the rehearsal set-up, never production -- the collective is done on a host copy."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def broadcast_tensors(tensors: List[torch.Tensor], src: int = 0, group=None) -> None:
+    """Overwrite ``tensors`` on every rank with rank ``src``'s values: one collective per dtype over a flat copy
+    instead of one per tensor."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for ts in by_dtype.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            if _host_staged(flat, group):
+                host = flat.cpu()
+                dist.broadcast(host, src=src, group=group)
+                flat = host.to(flat.device)
+            else:
+                dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
 
 
 class GradBucketer:
@@ -99,8 +133,13 @@ class GradBucketer:
         if end <= self.sent:
             return
         if self.world > 1:
-            self.works.append(dist.all_reduce(self.arena[self.sent:end], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+            piece = self.arena[self.sent:end]
+            if _host_staged(piece, self.group):
+                host = piece.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                piece.copy_(host)
+            else:
+                self.works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((self.sent, end))
         self.sent = end
 
