@@ -398,3 +398,30 @@ def test_training_step_with_deeper_freeze_matches_oracle(cuda):
     key = "backbone.bottom_up.res2.1.conv2.norm.running_var"
     assert torch.equal(bufs[key].cpu(), sd[key])
     model.eval()
+
+
+def test_inference_after_training_uses_the_updated_weights(cuda):
+    """train() -> a few optimizer steps -> eval(): the inference plan repacks the (now channels_last, arena-resident)
+    parameters and the updated running statistics, and its heads match the oracle on the current state dict."""
+    from oracle import yolo_ref as R
+    model, cfg, sd, imgs, gb, gc, inputs = _make("f32", N=2, S=64)
+    model.eval()
+    x = (imgs.float() / 255.0)
+    before = {k: v.clone() for k, v in model.backbone(x.to(cuda)).items()}
+    model.train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        sum(model(inputs).values()).backward()
+        opt.step()
+    model.eval()
+    now = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    assert not torch.equal(now["backbone.fpn_output2.head.weight"], sd["backbone.fpn_output2.head.weight"])
+    with torch.no_grad():
+        ref = R.fpn_forward(x, now)
+    out = model.backbone(x.to(cuda))
+    torch.cuda.synchronize()
+    for k in ("p3", "p4", "p5"):
+        got = out[k].float().cpu()
+        assert float((got - ref[k]).abs().max() / ref[k].abs().max()) < 1e-3, k
+        assert not torch.allclose(got, before[k].float().cpu())
