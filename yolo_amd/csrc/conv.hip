@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                 for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(buf + b_base + j * 16 * ROWB + ko);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMA block
+            __builtin_amdgcn_s_setprio(1);  // matrix work first when both co-resident workgroups have some (+1.5-2 %)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #pragma unroll
                     for (int j = 0; j < FP; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         } else {
             // f32 MFMA 16x16x4 takes ONE k per lane group; element e of each lane's 16-byte chunk feeds
             // MFMA e, the same k permutation on both operands.
