@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) b[kk][f] = frag(buf + kk * 32 * 256, b_off, f);
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -276,6 +277,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- partial tile -> this split's slab
