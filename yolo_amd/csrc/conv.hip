@@ -33,6 +33,8 @@ struct ConvParams {
     long long r_img_stride, r_origin;
     int r_row_stride, r_pix_stride;
     int Ho, Wo, M;      // conv output size, M = N*Ho*Wo
+    float inv_HoWo, inv_Wo;  // reciprocals for the pixel -> (n, ho, wo) split; used when M < 2^24 (fast_div)
+    int fast_div;
     int stride, ksize;  // conv stride, kernel size
     int cpt;            // 128-byte k-steps per tap (Cin*esize/128)
     int nsteps;         // k-steps in total
@@ -46,6 +48,37 @@ struct ConvParams {
 };
 
 constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
+
+// m -> (n, ho, wo).  Integer division by a run-time divisor costs ~40 instructions; for m < 2^24 a float
+// reciprocal and one correction step are exact and cost ~8.  Every lane does this for each of its tile rows in
+// the prologue and once per epilogue pass, which is felt on short-K layers.
+__device__ __forceinline__ void split_pixel(const ConvParams& p, int m, int HoWo, int& n, int& ho, int& wo) {
+    if (p.fast_div) {
+        n = (int)((float)m * p.inv_HoWo);
+        int r = m - n * HoWo;
+        if (r < 0) {
+            --n;
+            r += HoWo;
+        } else if (r >= HoWo) {
+            ++n;
+            r -= HoWo;
+        }
+        ho = (int)((float)r * p.inv_Wo);
+        wo = r - ho * p.Wo;
+        if (wo < 0) {
+            --ho;
+            wo += p.Wo;
+        } else if (wo >= p.Wo) {
+            ++ho;
+            wo -= p.Wo;
+        }
+    } else {
+        n = m / HoWo;
+        const int r = m - n * HoWo;
+        ho = r / p.Wo;
+        wo = r - ho * p.Wo;
+    }
+}
 
 __device__ __forceinline__ void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -99,10 +132,8 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         const int row = 8 * (wave + NW * i) + lrow;
         int m = tile_p * TP + row;
         m = m < p.M ? m : p.M - 1;  // tail rows read a valid pixel; their results are never stored
-        const int n = m / HoWo;
-        const int rem = m - n * HoWo;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
+        int n, ho, wo;
+        split_pixel(p, m, HoWo, n, ho, wo);
         xsrc[i] = p.x + p.x_origin + (long long)n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
                   (wo * p.stride) * p.x_pix_stride + (TAP2 ? (schunk & 3) : schunk) * 16;
     }
@@ -248,10 +279,8 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             const int px = pass * PPP + tid / G;
             const int m = tile_p * TP + half * HP + px;
             if (m >= p.M) break;
-            const int n = m / HoWo;
-            const int rem = m - n * HoWo;
-            const int ho = rem / p.Wo;
-            const int wo = rem - ho * p.Wo;
+            int n, ho, wo;
+            split_pixel(p, m, HoWo, n, ho, wo);
             const char* sp = smem + px * (TC * 4);
             f32x4 v0 = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
             f32x4 v1 = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
@@ -490,6 +519,10 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
     p.Ho = Ho;
     p.Wo = Wo;
     p.M = N * Ho * Wo;
+    p.inv_HoWo = 1.0f / (float)(Ho * Wo);
+    p.inv_Wo = 1.0f / (float)Wo;
+    static const bool int_div = getenv("YOLO_CONV_INTDIV") && atoi(getenv("YOLO_CONV_INTDIV"));
+    p.fast_div = p.M < (1 << 24) && !int_div;
     p.stride = stride;
     p.ksize = k;
     const int row_elems = ROWB / es;
