@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+# YOLO_HIP_LIB: another build of the same library (A/B measurements of kernel changes)
+LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "libyolo_hip.so")
 
 c_int, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.c_size_t)

@@ -257,6 +257,22 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     }
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
+    // bf16 residual: all of this lane's values for the half are requested before the tile is staged, so their
+    // latency hides behind the staging instead of adding up pass by pass
+    u32x4 rres[HP / PPP];
+    if constexpr (BF) {
+        if (p.res && ch_first < p.Cout) {
+#pragma unroll
+            for (int pass = 0; pass < HP / PPP; ++pass) {
+                int m = tile_p * TP + half * HP + pass * PPP + tid / G;
+                m = m < p.M ? m : p.M - 1;
+                int n, ho, wo;
+                split_pixel(p, m, HoWo, n, ho, wo);
+                rres[pass] = *(const u32x4*)(p.res + p.r_origin + (long long)n * p.r_img_stride +
+                                             (long long)ho * p.r_row_stride + wo * p.r_pix_stride + (size_t)ch_first * 2);
+            }
+        }
+    }
     __syncthreads();
     if (NH == 1 || wp == half) {
         const int ch0 = wc * (TC / WC) + q * 4;
@@ -274,7 +290,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     }
     __syncthreads();
     if (ch_first < p.Cout) {
-#pragma unroll 1
+#pragma unroll
         for (int pass = 0; pass < HP / PPP; ++pass) {
             const int px = pass * PPP + tid / G;
             const int m = tile_p * TP + half * HP + px;
@@ -285,10 +301,11 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             f32x4 v0 = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
             f32x4 v1 = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
             if (p.res) {
-                const char* rp = p.res + p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
-                                 wo * p.r_pix_stride + (size_t)ch_first * sizeof(T);
+                [[maybe_unused]] const char* rp = p.res + p.r_origin + (long long)n * p.r_img_stride +
+                                                  (long long)ho * p.r_row_stride + wo * p.r_pix_stride +
+                                                  (size_t)ch_first * sizeof(T);
                 if constexpr (BF) {
-                    const u32x4 r = *(const u32x4*)rp;
+                    const u32x4 r = rres[pass];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         v0[2 * e] += __uint_as_float(r[e] << 16);
