@@ -7,7 +7,6 @@ utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 256 CUs * 4 SIMDs), cycles = 
 reports the sum over the 8 XCDs).  MOPS_BF16 counts units of 512 FLOPs: FLOP/cycle/CU = 512 * MOPS / cycles / 256,
 against 4096 dense bf16 FLOP/cycle/CU on the matrix cores."""
 import csv
-import re
 import sys
 from collections import defaultdict
 

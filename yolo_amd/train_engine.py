@@ -345,8 +345,6 @@ class TrainEngine:
                 continue                   # its input comes from frozen layers: no data gradient
             L.dx = grad_of(L.x)
             kx = id(L.dx.buf)
-            if L.residual is None and self._is_conv1(L):
-                pass
             if self._is_conv1(L):          # block input also feeds the skip connection: + d(block output)
                 blk_out = P.layers[i + 1]
                 assert blk_out.residual is not None and blk_out.residual.buf is L.x.buf
