@@ -294,6 +294,19 @@ typedef struct yolo_pack_desc {
 int yolo_pack_conv_train_batch(const yolo_pack_desc* descs_device, int n_layers, int total_tiles, int dtype,
                                void* stream);
 
+/*
+ * Data gradient of a 3x3 / stride-2 / pad-1 convolution (ResidualBlock.downsample, darknet.py:79-82,113-116, under
+ * autograd) in one launch, bf16: dx = yolo_conv2d_fwd(yolo_dilate2x_nhwc(dz), w_dgrad_packed) without the dilated
+ * buffer and without multiplying its zeros -- every output pixel visits only the 1, 2 or 4 taps that can reach it.
+ *   dz        gradient view [Hi x Wi], Cin channels (the forward conv's output channels, padded to 64), zero halo >= 1
+ *   w_dgrad_packed, bias   the data-gradient packing yolo_pack_conv_train(_batch) writes; bias [>= Cout] f32 (zeros)
+ *   residual  NULL or a view of dx's geometry that is added (another consumer's gradient)
+ *   dx        output view [2Hi x 2Wi], Cout channels (the forward conv's input channels), Cout > 64
+ */
+int yolo_conv3x3s2_dgrad(const yolo_view* dz, const void* w_dgrad_packed, const float* bias,
+                         const yolo_view* residual, const yolo_view* dx, int N, int Cin, int Cout, int dtype,
+                         void* stream);
+
 /* y[2i][2j] = x[i][j], zeros elsewhere in each 2x2 cell (input of a stride-2 conv's data gradient). */
 int yolo_dilate2x_nhwc(const yolo_view* x, const yolo_view* y, int N, int C, int dtype, void* stream);
 /* y[i][j] = sum of the 2x2 cell of x: backward of nn.Upsample(2, "nearest") (fpn.py:31,36). */

@@ -221,3 +221,39 @@ def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1:], res[1][1:]):
         assert torch.isfinite(b).all() and _rel(b, a) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 256, 13, 13), (3, 256, 512, 7, 9), (1, 128, 128, 26, 20), (2, 512, 1024, 5, 5)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("with_residual", [False, True], ids=["plain", "accumulate"])
+def test_stride2_dgrad_without_dilation(cuda, shape, with_residual):
+    """yolo_conv3x3s2_dgrad against the form it replaces, yolo_dilate2x_nhwc + yolo_conv2d_fwd with the same
+    data-gradient weights: the same products are summed in the same order (the dilated form only adds zeros), so
+    the two agree bit for bit; and against torch's conv_transpose2d on the bf16-rounded operands."""
+    from yolo_amd import ops
+    N, c_in, c_out, Hi, Wi = shape            # forward conv: c_in -> c_out, 3x3, stride 2; dz has c_out channels
+    torch.manual_seed(23)
+    w = torch.randn(c_out, c_in, 3, 3) * (2.0 / (c_in * 9)) ** 0.5
+    cpad = (c_out + 63) // 64 * 64
+    wpad = torch.zeros(cpad, c_in, 3, 3)
+    wpad[:c_out] = w
+    wd, bd = ops.pack_conv_dgrad(wpad.to(cuda), torch.bfloat16, cuda)
+    dz = ops.alloc_view(N, Hi, Wi, cpad, 1, torch.bfloat16, cuda)
+    dz.interior()[..., :c_out].normal_()
+    other = ops.alloc_view(N, 2 * Hi, 2 * Wi, c_in, 1, torch.bfloat16, cuda)
+    other.interior().normal_()
+    res = other if with_residual else None
+    dzd = ops.alloc_view(N, 2 * Hi, 2 * Wi, cpad, 1, torch.bfloat16, cuda)
+    ops.dilate2x(dz, dzd)
+    want = ops.alloc_view(N, 2 * Hi, 2 * Wi, c_in, 1, torch.bfloat16, cuda)
+    ops.conv2d_fwd(dzd, wd, bd, want, cin=cpad, cout=c_in, k=3, stride=1, slope=1.0, residual=res)
+    got = ops.alloc_view(N, 2 * Hi, 2 * Wi, c_in, 1, torch.bfloat16, cuda)
+    got.buf.fill_(5.0)
+    ops.conv3x3s2_dgrad(dz, wd, bd, got, cin=cpad, cout=c_in, residual=res)
+    torch.cuda.synchronize()
+    assert torch.equal(got.interior(), want.interior())
+    assert float(got.buf[:, 0].min()) == 5.0 and float(got.buf[:, :, 0].min()) == 5.0   # the halo is not written
+    ref = F.conv_transpose2d(dz.nchw()[:, :c_out].float().cpu(), w.bfloat16().float(), stride=2, padding=1, output_padding=1)
+    if with_residual:
+        ref = ref + other.nchw().float().cpu()
+    assert _rel(got.nchw().float().cpu(), ref) < 5e-2

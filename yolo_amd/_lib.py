@@ -61,6 +61,7 @@ SIGNATURES = {
     "yolo_conv2d_bnsums_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "yolo_bn_train_finalize": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_float, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "yolo_conv3x3s2_dgrad": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                      c_void_p]),

@@ -44,6 +44,7 @@ struct ConvParams {
     float slope;
     int upsample;
     int y_f32;  // output element type is f32 (else bf16)
+    int Mc;        // S2D kernels: pixels per parity class (N * Hi * Wi); n_ptiles = 4 * tiles per class
     float* stats;  // STATS kernels: per pixel tile, per channel: [n_ptiles][2][Cout] sums of y and y*y
 };
 
@@ -89,8 +90,15 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // out WC x WP).  TAP2: bf16 with Cin == 32, one k-step spans two filter taps.
 // STATS: additionally leave, per pixel tile, the per-channel sums of the output values as stored (after rounding
 // to the output type) and of their squares -- the first pass of a training-mode BatchNorm over this output.
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false>
+//
+// S2D: data gradient of a 3x3 / stride-2 / pad-1 convolution without materialising the zero-dilated gradient.
+// x is dz [Hi x Wi], y is dx [2Hi x 2Wi]; output pixel (2i+a, 2j+b) only meets the taps kh' with a+kh'-1 even
+// (one for a = 0, two for a = 1; likewise kw'), at dz row i + (a+kh'-1)/2.  The pixels of a launch are
+// enumerated class by class ((a,b) = 00, 01, 10, 11), every tile lies inside one class and runs 1, 2, 2 or 4 of
+// the 9 taps: 9 tap-visits per 4 output pixels instead of 36.  p.Ho/p.Wo/p.Mc describe ONE class (= dz's grid).
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false>
 __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(const ConvParams p) {
+    static_assert(!(S2D && (TAP2 || STATS)), "S2D is a plain bf16/f32 convolution");
     static_assert(WC * WP == NW, "waves");
     constexpr bool BF = sizeof(T) == 2;
     constexpr int W_BYTES = TC * ROWB, X_BYTES = TP * ROWB, BUF = W_BYTES + X_BYTES;
@@ -115,6 +123,16 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         tile_c = logical % p.n_ctiles;
         tile_p = logical / p.n_ctiles;
     }
+    // S2D: parity class of this tile and its pixel range inside the class
+    int par_a = 0, par_b = 0, pix_base = tile_p * TP, pix_end = p.M;
+    if constexpr (S2D) {
+        const int tpc = p.n_ptiles >> 2;
+        const int cls = tile_p / tpc;
+        par_a = cls >> 1;
+        par_b = cls & 1;
+        pix_base = (tile_p - cls * tpc) * TP;
+        pix_end = p.Mc;
+    }
 
     // ---- loader set-up: each lane owns one 16-byte chunk of NWP weight rows and NXP pixel rows
     const int lrow = lane >> 3;
@@ -130,8 +148,8 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #pragma unroll
     for (int i = 0; i < NXP; ++i) {
         const int row = 8 * (wave + NW * i) + lrow;
-        int m = tile_p * TP + row;
-        m = m < p.M ? m : p.M - 1;  // tail rows read a valid pixel; their results are never stored
+        int m = pix_base + row;
+        m = m < pix_end ? m : pix_end - 1;  // tail rows read a valid pixel; their results are never stored
         int n, ho, wo;
         split_pixel(p, m, HoWo, n, ho, wo);
         xsrc[i] = p.x + p.x_origin + (long long)n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
@@ -153,7 +171,11 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         } else {
             xoff = cur_kh * p.x_row_stride + cur_kw * p.x_pix_stride + cur_cc * ROWB;
         }
-        const int woff = cur_step * ROWB;
+        int woff = cur_step * ROWB;
+        if constexpr (S2D) {  // cur_kh / cur_kw count the class's taps: tap kh' = 2*cur_kh (a = 1) or 1 (a = 0)
+            const int kh = par_a ? 2 * cur_kh : 1, kw = par_b ? 2 * cur_kw : 1;
+            woff = ((kh * 3 + kw) * p.cpt + cur_cc) * ROWB;
+        }
 #pragma unroll
         for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + NW * i) * 1024);
 #pragma unroll
@@ -161,7 +183,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         ++cur_step;
         if (++cur_cc == p.cpt) {
             cur_cc = 0;
-            if (++cur_kw == p.ksize) {
+            if (++cur_kw == (S2D ? 1 + par_b : p.ksize)) {
                 cur_kw = 0;
                 ++cur_kh;
             }
@@ -231,11 +253,12 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     };
 
     // ---- main loop: loads of step s+1 fly while step s is multiplied
+    const int nsteps = S2D ? (1 + par_a) * (1 + par_b) * p.cpt : p.nsteps;
     stage(smem);
-    for (int s = 0; s < p.nsteps; ++s) {
+    for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < p.nsteps) stage(smem + ((s + 1) & 1) * BUF);
+        if (s + 1 < nsteps) stage(smem + ((s + 1) & 1) * BUF);
         compute(smem + (s & 1) * BUF);
     }
     // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte chunks XOR-swizzled by
@@ -264,10 +287,14 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         if (p.res && ch_first < p.Cout) {
 #pragma unroll
             for (int pass = 0; pass < HP / PPP; ++pass) {
-                int m = tile_p * TP + half * HP + pass * PPP + tid / G;
-                m = m < p.M ? m : p.M - 1;
+                int m = pix_base + half * HP + pass * PPP + tid / G;
+                m = m < pix_end ? m : pix_end - 1;
                 int n, ho, wo;
                 split_pixel(p, m, HoWo, n, ho, wo);
+                if constexpr (S2D) {
+                    ho = 2 * ho + par_a;
+                    wo = 2 * wo + par_b;
+                }
                 rres[pass] = *(const u32x4*)(p.res + p.r_origin + (long long)n * p.r_img_stride +
                                              (long long)ho * p.r_row_stride + wo * p.r_pix_stride + (size_t)ch_first * 2);
             }
@@ -293,10 +320,14 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #pragma unroll
         for (int pass = 0; pass < HP / PPP; ++pass) {
             const int px = pass * PPP + tid / G;
-            const int m = tile_p * TP + half * HP + px;
-            if (m >= p.M) break;
+            const int m = pix_base + half * HP + px;
+            if (m >= pix_end) break;
             int n, ho, wo;
             split_pixel(p, m, HoWo, n, ho, wo);
+            if constexpr (S2D) {
+                ho = 2 * ho + par_a;
+                wo = 2 * wo + par_b;
+            }
             const char* sp = smem + px * (TC * 4);
             f32x4 v0 = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
             f32x4 v1 = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
@@ -384,12 +415,12 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     }
 }
 
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false>
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // two operand buffers, or the f32 epilogue staging tile if that is larger
     constexpr int OPS = 2 * (TC + TP) * ROWB, STG = TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4;
     constexpr int LDS = OPS > STG ? OPS : STG;
-    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS>;
+    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D>;
     static bool attr_set = false;
     if (!attr_set) {
         YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -595,4 +626,74 @@ extern "C" int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, 
     YOLO_REQUIRE(sums, "conv2d_fwd_bnsums: null argument");
     return conv2d_impl(x, w_packed, bias, nullptr, y, N, Cin, Cout, k, stride, 1.0f, 0, dtype, dtype, sums, sums_bytes,
                        stream);
+}
+
+extern "C" int yolo_conv3x3s2_dgrad(const yolo_view* dz, const void* w_dgrad_packed, const float* bias,
+                                    const yolo_view* residual, const yolo_view* dx, int N, int Cin, int Cout, int dtype,
+                                    void* stream) {
+    YOLO_REQUIRE(dz && dx && w_dgrad_packed && bias, "conv3x3s2_dgrad: null argument");
+    YOLO_REQUIRE(dtype == YOLO_BF16, "conv3x3s2_dgrad: bf16 only (dtype %d)", dtype);
+    YOLO_REQUIRE(N > 0 && Cin > 0 && Cin % 64 == 0 && Cout > 64, "conv3x3s2_dgrad: Cin %d (multiple of 64), Cout %d (> 64)", Cin, Cout);
+    YOLO_REQUIRE(dz->halo >= 1, "conv3x3s2_dgrad: the gradient view needs a zero halo");
+    YOLO_REQUIRE(dx->H == 2 * dz->H && dx->W == 2 * dz->W, "conv3x3s2_dgrad: output view %dx%d, expected %dx%d", dx->H, dx->W,
+                 2 * dz->H, 2 * dz->W);
+    const int Cout8 = (Cout + 7) / 8 * 8;
+    YOLO_REQUIRE(dz->ch_offset + Cin <= dz->ch_total && dz->ch_offset % 8 == 0 && dz->ch_total % 8 == 0,
+                 "conv3x3s2_dgrad: bad gradient channel slice");
+    YOLO_REQUIRE(dx->ch_offset + Cout8 <= dx->ch_total && dx->ch_offset % 8 == 0 && dx->ch_total % 8 == 0,
+                 "conv3x3s2_dgrad: bad output channel slice");
+    if (residual)
+        YOLO_REQUIRE(residual->H == dx->H && residual->W == dx->W && residual->ch_offset % 8 == 0 &&
+                         residual->ch_total % 8 == 0 && residual->ch_offset + Cout8 <= residual->ch_total,
+                     "conv3x3s2_dgrad: residual view mismatch");
+    const long long Mc = (long long)N * dz->H * dz->W;
+    YOLO_REQUIRE(4 * Mc < (1ll << 31), "conv3x3s2_dgrad: too many output pixels");
+    ConvParams p{};
+    p.x = (const char*)dz->ptr;
+    p.w = (const char*)w_dgrad_packed;
+    p.bias = bias;
+    p.res = residual ? (const char*)residual->ptr : nullptr;
+    p.y = (char*)dx->ptr;
+    const ViewGeom gx = geom_of(*dz), gy = geom_of(*dx);
+    p.x_img_stride = gx.img_stride * 2;
+    p.x_row_stride = gx.row_stride * 2;
+    p.x_pix_stride = gx.pix_stride * 2;
+    p.x_origin = (long long)gx.origin * 2;   // tap offsets are 0 or +1 rows / pixels: no shift by the padding
+    p.y_img_stride = gy.img_stride * 2;
+    p.y_row_stride = gy.row_stride * 2;
+    p.y_pix_stride = gy.pix_stride * 2;
+    p.y_origin = (long long)gy.origin * 2;
+    if (residual) {
+        const ViewGeom gr = geom_of(*residual);
+        p.r_img_stride = gr.img_stride * 2;
+        p.r_row_stride = gr.row_stride * 2;
+        p.r_pix_stride = gr.pix_stride * 2;
+        p.r_origin = (long long)gr.origin * 2;
+    }
+    p.Ho = dz->H;
+    p.Wo = dz->W;
+    p.Mc = (int)Mc;
+    p.M = (int)(4 * Mc);
+    p.inv_HoWo = 1.0f / (float)(dz->H * dz->W);
+    p.inv_Wo = 1.0f / (float)dz->W;
+    p.fast_div = Mc < (1 << 24);
+    p.stride = 1;
+    p.ksize = 3;
+    p.cpt = Cin / 64;
+    p.nsteps = 9 * p.cpt;
+    p.w_row_bytes = p.nsteps * ROWB;
+    p.Cout = Cout;
+    p.slope = 1.0f;
+    p.n_ctiles = (Cout + 127) / 128;
+    // tiles never straddle a class; the average tile runs 9/4 taps
+    const int tp = pick_tp(p.M, p.n_ctiles, 9 * p.cpt / 4);
+    const int tpc = (int)((Mc + tp - 1) / tp);
+    p.n_ptiles = 4 * tpc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tp) {
+        case 64: return launch_conv<bf16_t, 128, 64, 2, 2, false, 4, false, true>(p, st);
+        case 96: return launch_conv<bf16_t, 128, 96, 2, 2, false, 4, false, true>(p, st);
+        case 192: return launch_conv<bf16_t, 128, 192, 2, 2, false, 4, false, true>(p, st);
+        default: return launch_conv<bf16_t, 128, 128, 2, 2, false, 4, false, true>(p, st);
+    }
 }

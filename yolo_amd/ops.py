@@ -552,3 +552,16 @@ def bn_train_finalize(sums: torch.Tensor, rows: int, count: int, gamma: torch.Te
     check(lib().yolo_bn_train_finalize(_ptr(sums), rows, count, C, _ptr(gamma), _ptr(beta), eps, momentum,
                                        _ptr(running_mean), _ptr(running_var), _ptr(stats), _stream()),
           "yolo_bn_train_finalize")
+
+
+def conv3x3s2_dgrad(dz: View, w_dgrad: torch.Tensor, bias: torch.Tensor, dx: View, *, cin: int, cout: int,
+                    residual: Optional[View] = None) -> None:
+    """Data gradient of a 3x3 / stride-2 convolution straight from the undilated gradient (bf16): dx [2H x 2W, cout]
+    from dz [H x W, cin]; ``residual`` is added (another consumer's gradient)."""
+    _require_cuda(dz.buf, "conv3x3s2_dgrad")
+    assert dz.buf.dtype == torch.bfloat16 and dx.buf.dtype == torch.bfloat16 and w_dgrad.dtype == torch.bfloat16
+    zv, xv = dz.c(), dx.c()
+    rv = residual.c() if residual is not None else None
+    check(lib().yolo_conv3x3s2_dgrad(ctypes.byref(zv), _ptr(w_dgrad), _ptr(bias), ctypes.byref(rv) if rv is not None else None,
+                                     ctypes.byref(xv), dz.N, cin, cout, dtype_code(dz.buf.dtype), _stream()),
+          "yolo_conv3x3s2_dgrad")

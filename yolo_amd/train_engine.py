@@ -250,8 +250,8 @@ class TrainEngine:
                     L.z = A(ho, wo, conv.out_channels, 0)
                     L.stats = torch.zeros(5, conv.out_channels, device=dev)
                     L.dz = A(ho, wo, conv.out_channels)
-                if conv.stride == 2:
-                    L.dzd = A(2 * ho, 2 * wo, conv.out_channels)
+                if conv.stride == 2 and not (dt == torch.bfloat16 and conv.kernel_size == 3 and conv.in_channels > 64):
+                    L.dzd = A(2 * ho, 2 * wo, conv.out_channels)   # zero-dilated dz for the generic data-gradient form
             P.layers.append(L)
             return L
 
@@ -478,10 +478,13 @@ class TrainEngine:
             w, b = self._packed(L.name, "dgrad")
             cpad = (c.out_channels + 63) // 64 * 64
             src = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, cpad, 0)
+            res = L.dx_add if L.dx_add is not None else (L.dx if L.dx_accumulate else None)
+            if c.stride == 2 and L.dzd is None:   # bf16: straight from dz, only the taps that reach each output pixel
+                ops.conv3x3s2_dgrad(src, w, b, L.dx, cin=cpad, cout=c.in_channels, residual=res)
+                continue
             if c.stride == 2:
                 ops.dilate2x(src, L.dzd)
                 src = L.dzd
-            res = L.dx_add if L.dx_add is not None else (L.dx if L.dx_accumulate else None)
             ops.conv2d_fwd(src, w, b, L.dx, cin=cpad, cout=c.in_channels, k=c.kernel_size, stride=1, slope=1.0, residual=res)
         if ddp:
             P.bucketer.finish()
