@@ -344,6 +344,62 @@ int yolo_train_loss_bwd(const yolo_view* head, const yolo_view* dhead, int dhead
                         const int* gt_classes, const int* gt_count, int K, float obj_weight, float noobj_weight,
                         const float* grad_losses, void* workspace, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training-image augmentation on the device.  Images are uint8, HWC, 3 channels, rows `stride` bytes apart.
+ * The reference runs these steps per image on CPU workers through OpenCV / Pillow.
+ * ------------------------------------------------------------------------------------------------ */
+
+/*
+ * LetterBoxTransform.apply_image (yolo/data/transforms.py:207-212): cv2.resize(INTER_LINEAR) of the source to
+ * resized_height x resized_width (skipped when the size is unchanged), placed at (top, left) of a
+ * dst_height x dst_width image whose other pixels take border_value (114 in the reference).
+ */
+int yolo_aug_letterbox(const void* src, int src_height, int src_width, long long src_stride, void* dst,
+                       int dst_height, int dst_width, long long dst_stride, int top, int left, int resized_height,
+                       int resized_width, int border_value, void* stream);
+
+/*
+ * The resize detectron2's ResizeShortestEdge applies to a uint8 image (yolo/data/detection_utils.py:55,96-104;
+ * Predictor, tools/inference.py:36-45): Pillow's Image.resize(BILINEAR) -- a triangle filter widened by the
+ * down-scaling factor, 22-bit integer coefficients, horizontal pass into a uint8 intermediate, then vertical.
+ *   x_bounds [dst_width][2] i32 (first source column, count), x_coef [dst_width][x_ksize] i32: device tables of
+ *   the horizontal pass (NULL when the width does not change); y_* likewise for the vertical pass.
+ *   workspace: yolo_aug_resample_workspace_bytes(src_height, dst_width) bytes, needed when both sizes change.
+ */
+int yolo_aug_resample(const void* src, int src_height, int src_width, long long src_stride, void* dst,
+                      int dst_height, int dst_width, long long dst_stride, const int* x_bounds, const int* x_coef,
+                      int x_ksize, const int* y_bounds, const int* y_coef, int y_ksize, void* workspace,
+                      size_t workspace_bytes, void* stream);
+size_t yolo_aug_resample_workspace_bytes(int src_height, int dst_width);
+
+/*
+ * One image's remaining augmentation as ONE pass: AffineTransform.apply_image (transforms.py:43-50: cv2.warpAffine /
+ * cv2.warpPerspective, INTER_LINEAR, constant border) -> ColorJitterTransform.apply_image (transforms.py:177-186:
+ * to HSV, three 256-entry tables, back) -> RandomFlip -> the crop [crop_y : crop_y + crop_h, crop_x : crop_x + crop_w]
+ * of that result written at (dst_y, dst_x) of the destination (YOLOV3DatasetMapper._blend_mosaic,
+ * yolo/data/dataset_mapper.py:136-152; crop = whole image and dst = a same-sized image without mosaic).
+ * The augmented image has the source's size.
+ *   warp         0 none, 1 affine (inverse_map[0..5]), 2 perspective (inverse_map[0..8]); the map takes output
+ *                pixels to source pixels, i.e. it is the INVERSE of AffineTransform.M
+ *   jitter       0 / 1; hue_gain, saturation_gain, exposure_gain as ColorJitterTransform's arguments
+ *   rgb_order    1 if channel 0 is red (INPUT.FORMAT "RGB"), 0 for BGR
+ *   dst_plane_stride  0: dst is HWC like the source (dst_stride >= 3 * dst_width); otherwise dst is CHW -- the
+ *                layout the model's batched_inputs carry (dataset_mapper.py:132) -- with planes this many bytes
+ *                apart and rows dst_stride >= dst_width bytes apart
+ */
+typedef struct yolo_aug_job {
+    const void* src;
+    void* dst;
+    long long src_stride, dst_stride, dst_plane_stride;
+    int src_height, src_width, dst_height, dst_width;
+    int dst_x, dst_y, crop_x, crop_y, crop_w, crop_h;
+    int warp, jitter, rgb_order, flip_horizontal, flip_vertical, border;
+    double inverse_map[9];
+    double hue_gain, saturation_gain, exposure_gain;
+} yolo_aug_job;
+/* jobs: HOST array (copied into the launch); any number, 16 images per launch. */
+int yolo_aug_apply(const yolo_aug_job* jobs, int n_jobs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

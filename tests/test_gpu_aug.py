@@ -1,0 +1,303 @@
+"""GPU parity of the augmentation kernels (yolo_aug_letterbox / yolo_aug_resample / yolo_aug_apply, called through
+the C ABI by yolo_amd.ops and yolo_amd.data) against the CPU oracle oracle/aug_ref.py, which restates
+yolo/data/transforms.py, augmentation_impl.py and dataset_mapper.py with OpenCV's / Pillow's 8-bit algorithms.
+
+The work is bytes and integers: every comparison is BIT-EXACT.  The resize that Pillow performs is additionally
+compared with Pillow itself when it is importable on the box.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _img(h, w, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # smooth part + flat patches: exercises S = 0 / equal-channel branches of the colour conversion
+    a[: h // 3, : w // 2] = rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)
+    a[h // 2:, w // 2:, :] = a[h // 2:, w // 2:, :1]
+    return a
+
+
+def _dev(a, cuda):
+    return torch.from_numpy(a).to(cuda)
+
+
+@pytest.mark.parametrize("h,w,new_h,new_w", [(48, 64, 64, 64), (64, 48, 64, 64), (100, 37, 50, 80), (37, 53, 111, 160),
+                                            (64, 64, 64, 64), (480, 640, 640, 640), (3, 5, 32, 32), (1, 7, 8, 8)])
+def test_letterbox_matches_oracle(cuda, h, w, new_h, new_w):
+    from oracle import aug_ref as A
+    from yolo_amd.data import LetterBox
+    img = _img(h, w, h * 1000 + w)
+    t = LetterBox(new_h, new_w).get_transform(img)
+    got = t.apply_image(_dev(img, cuda)).cpu().numpy()
+    top, left, ratio, new_size = A.letterbox_params(h, w, new_h, new_w)
+    assert (t.top, t.left, t.new_size) == (top, left, new_size)
+    want = A.letterbox_apply(img, top, left, new_size)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("h,w,new_h,new_w", [(48, 64, 30, 40), (37, 53, 37, 20), (20, 31, 45, 77), (100, 60, 33, 60),
+                                            (64, 64, 64, 64), (7, 9, 3, 2), (480, 640, 416, 555), (375, 500, 640, 853)])
+def test_resample_matches_oracle_and_pillow(cuda, h, w, new_h, new_w):
+    from oracle import aug_ref as A
+    from yolo_amd import ops
+    img = _img(h, w, h * 7 + w)
+    got = ops.aug_resample(_dev(img, cuda), (new_h, new_w)).cpu().numpy()
+    assert np.array_equal(got, A.pil_resize_bilinear(img, (new_h, new_w)))
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(got, np.asarray(Image.fromarray(img).resize((new_w, new_h), Image.BILINEAR)))
+
+
+def _affine(h, w, seed, degree=10.0, perspective=0.0):
+    from yolo_amd.data import RandomAffine
+    np.random.seed(seed)
+    random.seed(seed)
+    return RandomAffine(translate=0.1, scale=0.3, degree=degree, shear=10.0, perspective=perspective).get_transform(
+        np.empty((h, w, 3), np.uint8))
+
+
+@pytest.mark.parametrize("h,w,seed", [(64, 64, 0), (97, 131, 1), (131, 97, 2), (640, 640, 3), (33, 200, 4)])
+def test_affine_warp_matches_oracle(cuda, h, w, seed):
+    from oracle import aug_ref as A
+    img = _img(h, w, seed)
+    t = _affine(h, w, seed)
+    M = A.affine_matrix(h, w, t.angle, t.scale, t.translate, t.shear, t.perspective)
+    assert np.array_equal(M, t.M)
+    got = t.apply_image(_dev(img, cuda)).cpu().numpy()
+    want = A.warp_affine(img, M)
+    assert np.array_equal(got, want)
+    assert (want == 114).all(-1).any() and (want != 114).any()  # border and picture both present
+
+
+@pytest.mark.parametrize("h,w,seed", [(64, 64, 10), (97, 131, 11), (200, 150, 12)])
+def test_perspective_warp_matches_oracle(cuda, h, w, seed):
+    from oracle import aug_ref as A
+    img = _img(h, w, seed)
+    t = _affine(h, w, seed, perspective=0.0008)
+    got = t.apply_image(_dev(img, cuda)).cpu().numpy()
+    assert np.array_equal(got, A.warp_perspective(img, t.M))
+
+
+def test_identity_warp_returns_the_image(cuda):
+    from yolo_amd.data import AffineTransform
+    img = _img(120, 77, 5)
+    t = AffineTransform(120, 77, translate=(0.5, 0.5))  # translate undoes the centring: M = identity
+    assert np.array_equal(t.M, np.eye(3))
+    assert np.array_equal(t.apply_image(_dev(img, cuda)).cpu().numpy(), img)
+
+
+@pytest.mark.parametrize("rgb", [False, True])
+@pytest.mark.parametrize("gains", [(1.0, 1.0, 1.0), (0.93, 1.41, 0.62), (1.1, 0.5, 1.5), (0.9, 2.5, 2.5)])
+def test_colour_jitter_matches_oracle(cuda, rgb, gains):
+    from oracle import aug_ref as A
+    from yolo_amd.data import transforms as T
+    # every (max, min) pair and many hues: a 256 x 256 sweep plus noise
+    g = np.arange(256, dtype=np.uint8)
+    sweep = np.stack([np.broadcast_to(g[:, None], (256, 256)), np.broadcast_to(g[None, :], (256, 256)),
+                      np.broadcast_to(((g[:, None].astype(int) * 3 + g[None, :] * 5) % 256).astype(np.uint8), (256, 256))], -1)
+    img = np.concatenate([sweep, sweep[..., ::-1], sweep[..., [1, 2, 0]], _img(64, 256, 3)], 0)
+    fmt = (T.COLOR_RGB2HSV, T.COLOR_HSV2RGB) if rgb else (T.COLOR_BGR2HSV, T.COLOR_HSV2BGR)
+    got = T.ColorJitterTransform(*gains, fmt).apply_image(_dev(np.ascontiguousarray(img), cuda)).cpu().numpy()
+    assert np.array_equal(got, A.color_jitter(img, *gains, rgb))
+
+
+def test_flips(cuda):
+    from yolo_amd.data import HFlipTransform, VFlipTransform
+    img = _img(45, 71, 8)
+    d = _dev(img, cuda)
+    assert np.array_equal(HFlipTransform(71).apply_image(d).cpu().numpy(), img[:, ::-1])
+    assert np.array_equal(VFlipTransform(45).apply_image(d).cpu().numpy(), img[::-1])
+    assert np.array_equal(HFlipTransform(71).apply_image(HFlipTransform(71).apply_image(d)).cpu().numpy(), img)
+
+
+@pytest.mark.parametrize("planar", [False, True])
+def test_fused_pass_equals_the_sequence_and_pastes_a_crop(cuda, planar):
+    """warp -> jitter -> flip -> crop -> paste in one launch for several images = the oracle's steps one by one."""
+    from oracle import aug_ref as A
+    from yolo_amd import ops
+    from yolo_amd.data import transforms as T
+    canvas_np = np.full((300, 400, 3), 114, np.uint8)
+    canvas = torch.full((3, 300, 400) if planar else (300, 400, 3), 114, dtype=torch.uint8, device=cuda)
+    jobs, keep = [], []
+    places = [((0, 0), (10, 20, 150, 100)), ((200, 0), (0, 0, 200, 130)), ((0, 150), (30, 0, 120, 150)),
+              ((200, 150), (0, 0, 97, 77)), ((130, 120), (5, 5, 40, 20))] + [((120 + (i % 4) * 20, 150 + (i // 4) * 20), (0, 0, 16, 16)) for i in range(14)]
+    for i, (dst_xy, crop) in enumerate(places):  # 19 jobs: more than one launch
+        h, w = 160 + 7 * (i % 5), 200 + 3 * (i % 5)
+        img = _img(h, w, 40 + i)
+        t = _affine(h, w, 40 + i)
+        gains = (0.9 + 0.02 * i, 0.6 + 0.1 * i, 1.4 - 0.05 * i)
+        tail = [t, T.ColorJitterTransform(*gains, (T.COLOR_RGB2HSV, T.COLOR_HSV2RGB))]
+        if i % 2:
+            tail.append(T.HFlipTransform(w))
+        elif i % 3 == 0:
+            tail.append(T.VFlipTransform(h))
+        d = _dev(img, cuda)
+        keep.append(d)
+        jobs.append(T.fused_job(tail, d, canvas, dst_xy=dst_xy, crop=crop, planar=planar))
+        want = A.color_jitter(A.warp_affine(img, t.M), *gains, True)
+        want = want[:, ::-1] if i % 2 else (want[::-1] if i % 3 == 0 else want)
+        cx, cy, cw, ch = crop
+        canvas_np[dst_xy[1]:dst_xy[1] + ch, dst_xy[0]:dst_xy[0] + cw] = want[cy:cy + ch, cx:cx + cw]
+    ops.aug_apply(jobs)
+    got = canvas.permute(1, 2, 0).cpu().numpy() if planar else canvas.cpu().numpy()
+    assert np.array_equal(got, canvas_np)
+
+
+def test_bad_arguments_are_rejected(cuda):
+    from yolo_amd import ops
+    img = _dev(_img(32, 32, 0), cuda)
+    small = torch.empty((16, 16, 3), dtype=torch.uint8, device=cuda)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.aug_apply([ops.aug_job(img, small)])  # the crop (whole image) does not fit the destination
+    with pytest.raises(RuntimeError, match="does not fit"):
+        ops.aug_letterbox(img, (16, 16), 0, 0, (32, 32))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.aug_resample(torch.zeros((8, 8, 3), dtype=torch.uint8), (4, 4))
+
+
+def _dataset(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        h, w = int(rng.integers(200, 420)), int(rng.integers(200, 420))
+        k = int(rng.integers(0, 6))
+        x0, y0 = rng.uniform(0, w - 40, k), rng.uniform(0, h - 40, k)
+        bw, bh = rng.uniform(8, 120, k), rng.uniform(8, 120, k)
+        annos = [dict(bbox=[x0[j], y0[j], min(x0[j] + bw[j], w), min(y0[j] + bh[j], h)], bbox_mode=0,
+                      category_id=int(rng.integers(0, 80)), iscrowd=int(j == 4)) for j in range(k)]
+        if k > 1:  # one XYWH annotation
+            b = annos[1]["bbox"]
+            annos[1].update(bbox=[b[0], b[1], b[2] - b[0], b[3] - b[1]], bbox_mode=1)
+        out.append(dict(image=_img(h, w, seed * 100 + i), height=h, width=w, image_id=i, annotations=annos))
+    return out
+
+
+def _expected(mapper, dataset, A):
+    """Replays the mapper's host-side decisions (same generators, same order) with the oracle's pixel functions."""
+    from yolo_amd.data import transforms as T
+
+    def load(d):
+        img = d["image"][:, :, ::-1] if mapper.image_format == "RGB" else d["image"]
+        tf = mapper.augmentations.plan(img)
+        x = np.ascontiguousarray(img)
+        for t in tf.transforms:
+            if isinstance(t, T.ResizeTransform):
+                x = A.pil_resize_bilinear(x, (t.new_h, t.new_w))
+            elif isinstance(t, T.LetterBoxTransform):
+                x = A.letterbox_apply(x, t.top, t.left, t.new_size)
+            elif isinstance(t, T.AffineTransform):
+                x = A.warp_perspective(x, t.M) if any(t.perspective) else A.warp_affine(x, t.M)
+            elif isinstance(t, T.ColorJitterTransform):
+                x = A.color_jitter(x, t.hue, t.saturation, t.exposure, t.rgb)
+            elif isinstance(t, T.HFlipTransform):
+                x = A.hflip(x)
+            elif isinstance(t, T.VFlipTransform):
+                x = A.vflip(x)
+        boxes = []
+        for a in d["annotations"]:
+            if a.get("iscrowd", 0):
+                continue
+            b = np.asarray(a["bbox"], np.float64)
+            if a["bbox_mode"] == 1:
+                b = np.array([b[0], b[1], b[0] + b[2], b[1] + b[3]])
+            boxes.append(b)
+        fns = []
+        for t in tf.transforms:
+            if isinstance(t, T.ResizeTransform):
+                fns.append(lambda c, t=t: c * np.array([t.new_w * 1.0 / t.w, t.new_h * 1.0 / t.h]))
+            elif isinstance(t, T.LetterBoxTransform):
+                fns.append(lambda c, t=t: A.letterbox_coords(c, t.ratio, t.top, t.left))
+            elif isinstance(t, T.AffineTransform):
+                fns.append(lambda c, t=t: A.affine_coords(c, t.M, t.height, t.width, any(t.perspective)))
+            elif isinstance(t, T.HFlipTransform):
+                fns.append(lambda c, t=t: A.flip_coords(c, 0, t.width, True))
+            elif isinstance(t, T.VFlipTransform):
+                fns.append(lambda c, t=t: A.flip_coords(c, t.height, 0, False))
+        bx = A.transform_boxes(np.array(boxes).reshape(-1, 4), fns, x.shape[:2])
+        return x, bx
+
+    results, pool, mt = [], [], mapper.mosaic_transform
+    for d in dataset:
+        samples = None
+        if mt.ENABLE:
+            if len(pool) > mt.NUM_IMAGES:
+                np.random.randint(2)
+                samples = [pool[int(i)] for i in np.random.choice(len(pool), mt.NUM_IMAGES - 1)]
+            pool.append(d)
+            pool = pool[-mt.POOL_CAPACITY:]
+        img, bx = load(d)
+        if samples is not None:
+            yc, xc = [int(np.random.uniform(-x, s * 2 + x)) for x, s in
+                      zip((-mt.MOSAIC_HEIGHT // 2, -mt.MOSAIC_WIDTH // 2), [mt.MOSAIC_HEIGHT, mt.MOSAIC_WIDTH])]
+            parts = [(img, bx)] + [load(s) for s in samples]
+            img, bx = A.mosaic_blend([p[0] for p in parts], [p[1] for p in parts], xc, yc, mt.MOSAIC_WIDTH, mt.MOSAIC_HEIGHT)
+        b32 = bx.astype(np.float32)
+        keep = ((b32[:, 2] - b32[:, 0]) > 1e-5) & ((b32[:, 3] - b32[:, 1]) > 1e-5) if len(bx) else np.zeros(0, bool)
+        results.append((img, bx[keep] if len(bx) else bx))
+    return results
+
+
+@pytest.mark.parametrize("config,opts", [
+    ("yolov3-aug.yaml", ["INPUT.MIN_SIZE_TRAIN", (320,), "INPUT.MAX_SIZE_TRAIN", 320, "INPUT.MOSAIC.MOSAIC_WIDTH", 320,
+                         "INPUT.MOSAIC.MOSAIC_HEIGHT", 320]),
+    ("yolov3-aug.yaml", ["INPUT.MOSAIC.ENABLE", False, "INPUT.LETTERBOX.HEIGHT", 320, "INPUT.LETTERBOX.WIDTH", 320,
+                         "INPUT.RANDOM_AFFINE.DEGREE", 5]),
+])
+def test_dataset_mapper_matches_the_oracle_pipeline(cuda, config, opts):
+    """YOLOV3DatasetMapper over 12 synthetic images (mosaics from the 6th on): image bytes and boxes equal the
+    oracle's sequential pipeline driven by the same random draws; both call styles agree."""
+    import os
+    from oracle import aug_ref as A
+    from yolo_amd.config import get_cfg
+    from yolo_amd.data import YOLOV3DatasetMapper
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", config))
+    cfg.merge_from_list(list(opts))
+    data = _dataset(12, 3)
+    for style in ("call", "batch"):
+        np.random.seed(11)
+        random.seed(11)
+        mapper = YOLOV3DatasetMapper(cfg, True)
+        outs = [mapper(d) for d in data] if style == "call" else mapper.map_batch(data)
+        np.random.seed(11)
+        random.seed(11)
+        want = _expected(YOLOV3DatasetMapper(cfg, True), data, A)
+        n_mosaic = 0
+        for o, (img, bx) in zip(outs, want):
+            got = o["image"]
+            assert got.dtype == torch.uint8 and got.is_cuda and got.shape[0] == 3
+            assert np.array_equal(got.permute(1, 2, 0).cpu().numpy(), img)
+            n_mosaic += img.shape[0] == 2 * cfg.INPUT.MOSAIC.MOSAIC_HEIGHT and cfg.INPUT.MOSAIC.ENABLE
+            if len(bx):
+                assert np.array_equal(o["instances"].gt_boxes.tensor.numpy(), bx.astype(np.float32))
+            else:
+                assert "instances" not in o or len(o["instances"]) == 0
+            assert "annotations" not in o
+        assert n_mosaic == (7 if cfg.INPUT.MOSAIC.ENABLE else 0)
+
+
+def test_mapper_output_feeds_the_training_step(cuda):
+    """The mapper's dicts are what the model's training step takes (device CHW uint8 + Instances)."""
+    import workload
+    from yolo_amd.data import YOLOV3DatasetMapper
+    model, cfg = workload.build_model(config="yolov3-aug.yaml", dtype="bf16",
+                                      opts=["INPUT.MIN_SIZE_TRAIN", (160,), "INPUT.MAX_SIZE_TRAIN", 160,
+                                            "INPUT.MOSAIC.MOSAIC_WIDTH", 160, "INPUT.MOSAIC.MOSAIC_HEIGHT", 160])
+    np.random.seed(0)
+    random.seed(0)
+    mapper = YOLOV3DatasetMapper(cfg, True)
+    outs = mapper.map_batch(_dataset(10, 5))[6:]  # the mosaics: all 320 x 320
+    assert all(o["image"].shape == (3, 320, 320) for o in outs)
+    model.train()
+    losses = model([o for o in outs if "instances" in o and len(o["instances"])])
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()

@@ -187,7 +187,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
-    assert L.yolo_abi_version() == 5
+    assert L.yolo_abi_version() == 6
     assert L.yolo_conv_cout_pad(255) == 256 and L.yolo_conv_cout_pad(32) == 128
 
 

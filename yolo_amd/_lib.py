@@ -26,6 +26,21 @@ _VP = ctypes.POINTER(YoloView)
 _IP = ctypes.POINTER(c_int)
 _FP = ctypes.POINTER(c_float)
 
+class AugJob(ctypes.Structure):
+    """``yolo_aug_job`` of include/yolo_hip.h."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+                ("src_stride", ctypes.c_longlong), ("dst_stride", ctypes.c_longlong),
+                ("dst_plane_stride", ctypes.c_longlong),
+                ("src_height", ctypes.c_int), ("src_width", ctypes.c_int), ("dst_height", ctypes.c_int),
+                ("dst_width", ctypes.c_int),
+                ("dst_x", ctypes.c_int), ("dst_y", ctypes.c_int), ("crop_x", ctypes.c_int), ("crop_y", ctypes.c_int),
+                ("crop_w", ctypes.c_int), ("crop_h", ctypes.c_int),
+                ("warp", ctypes.c_int), ("jitter", ctypes.c_int), ("rgb_order", ctypes.c_int),
+                ("flip_horizontal", ctypes.c_int), ("flip_vertical", ctypes.c_int), ("border", ctypes.c_int),
+                ("inverse_map", ctypes.c_double * 9),
+                ("hue_gain", ctypes.c_double), ("saturation_gain", ctypes.c_double), ("exposure_gain", ctypes.c_double)]
+
+
 # name -> (restype, argtypes); one entry per declaration in include/yolo_hip.h
 SIGNATURES = {
     "yolo_last_error": (ctypes.c_char_p, []),
@@ -61,6 +76,12 @@ SIGNATURES = {
     "yolo_conv2d_bnsums_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "yolo_bn_train_finalize": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_float, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "yolo_aug_letterbox": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, ctypes.c_longlong,
+                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "yolo_aug_resample": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, ctypes.c_longlong,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "yolo_aug_resample_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "yolo_aug_apply": (c_int, [c_void_p, c_int, c_void_p]),
     "yolo_conv3x3s2_dgrad": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,

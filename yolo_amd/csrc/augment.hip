@@ -1,0 +1,428 @@
+// Training-image augmentation on the device: uint8 HWC (3 channels) in, uint8 HWC out.
+//
+//   yolo_aug_letterbox  OpenCV-style 8-bit linear resize into a bordered destination
+//                       (LetterBoxTransform.apply_image, yolo/data/transforms.py:207-212)
+//   yolo_aug_resample   Pillow-style antialiased bilinear resize, two integer passes
+//                       (detectron2 ResizeShortestEdge, yolo/data/detection_utils.py:96-104)
+//   yolo_aug_apply      one pass per image: affine / perspective warp with the constant 114 border
+//                       (AffineTransform.apply_image, transforms.py:43-50) -> HSV colour jitter
+//                       (ColorJitterTransform.apply_image, transforms.py:177-186) -> flip -> paste of a crop
+//                       into a canvas (YOLOV3DatasetMapper._blend_mosaic, yolo/data/dataset_mapper.py:136-152)
+//
+// All arithmetic that decides an output byte is integer or correctly-rounded IEEE (no contraction: the file is
+// built with -ffp-contract=off), so results equal a CPU evaluation of the same formulas bit for bit.
+// The work is bound by memory: ~3 bytes written and 3-12 (cached) bytes read per pixel.
+#include "common.h"
+
+namespace yolo {
+
+static constexpr int AUG_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------------
+// letterbox: resize (11-bit coefficients per axis, the vertical blend on values shifted down by 4) + border
+// ------------------------------------------------------------------------------------------------
+struct LetterboxParams {
+    const uint8_t* src;
+    uint8_t* dst;
+    long long s_stride, d_stride;
+    int sh, sw, dh, dw, top, left, rh, rw, border;
+    double scale_x, scale_y;
+};
+
+__device__ __forceinline__ void linear_axis(int d, double scale, int n_src, int& s, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) {
+        f = 0.f;
+        s = 0;
+    }
+    if (s >= n_src - 1) {
+        f = 0.f;
+        s = n_src - 1;
+    }
+    c0 = (int)rintf((1.f - f) * 2048.f);
+    c1 = (int)rintf(f * 2048.f);
+}
+
+__global__ void __launch_bounds__(AUG_THREADS) aug_letterbox_kernel(const LetterboxParams p) {
+    const long long idx = (long long)blockIdx.x * AUG_THREADS + threadIdx.x;
+    if (idx >= (long long)p.dh * p.dw) return;
+    const int y = (int)(idx / p.dw), x = (int)(idx - (long long)y * p.dw);
+    uint8_t* o = p.dst + y * p.d_stride + 3 * x;
+    const int ry = y - p.top, rx = x - p.left;
+    if (ry < 0 || ry >= p.rh || rx < 0 || rx >= p.rw) {
+        o[0] = o[1] = o[2] = (uint8_t)p.border;
+        return;
+    }
+    if (p.rh == p.sh && p.rw == p.sw) {
+        const uint8_t* s = p.src + ry * p.s_stride + 3 * rx;
+        o[0] = s[0];
+        o[1] = s[1];
+        o[2] = s[2];
+        return;
+    }
+    int sx, cx0, cx1, sy, cy0, cy1;
+    linear_axis(rx, p.scale_x, p.sw, sx, cx0, cx1);
+    linear_axis(ry, p.scale_y, p.sh, sy, cy0, cy1);
+    const int sx1 = min(sx + 1, p.sw - 1), sy1 = min(sy + 1, p.sh - 1);
+    const uint8_t* r0 = p.src + sy * p.s_stride;
+    const uint8_t* r1 = p.src + sy1 * p.s_stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int a0 = r0[3 * sx + c] * cx0 + r0[3 * sx1 + c] * cx1;
+        const int a1 = r1[3 * sx + c] * cx0 + r1[3 * sx1 + c] * cx1;
+        int v = (((cy0 * (a0 >> 4)) >> 16) + ((cy1 * (a1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        o[c] = (uint8_t)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resample: out[o] = clip8((2^21 + sum_k in[first(o) + k] * coef[o][k]) >> 22) along one axis
+// ------------------------------------------------------------------------------------------------
+struct ResampleParams {
+    const uint8_t* src;
+    uint8_t* dst;
+    long long s_stride, d_stride;
+    int out_h, out_w;  // of this pass
+    const int* bounds;  // [n_out][2]: first source index, count
+    const int* coef;    // [n_out][ksize]
+    int ksize;
+};
+
+template <bool HORIZONTAL>
+__global__ void __launch_bounds__(AUG_THREADS) aug_resample_kernel(const ResampleParams p) {
+    const long long idx = (long long)blockIdx.x * AUG_THREADS + threadIdx.x;
+    if (idx >= (long long)p.out_h * p.out_w) return;
+    const int y = (int)(idx / p.out_w), x = (int)(idx - (long long)y * p.out_w);
+    const int o = HORIZONTAL ? x : y;
+    const int first = p.bounds[2 * o], n = p.bounds[2 * o + 1];
+    const int* k = p.coef + (long long)o * p.ksize;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    const uint8_t* s = HORIZONTAL ? p.src + y * p.s_stride + 3 * first : p.src + first * p.s_stride + 3 * x;
+    const long long step = HORIZONTAL ? 3 : p.s_stride;
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+        a0 += s[0] * w;
+        a1 += s[1] * w;
+        a2 += s[2] * w;
+        s += step;
+    }
+    uint8_t* d = p.dst + y * p.d_stride + 3 * x;
+    a0 >>= 22;
+    a1 >>= 22;
+    a2 >>= 22;
+    d[0] = (uint8_t)(a0 < 0 ? 0 : (a0 > 255 ? 255 : a0));
+    d[1] = (uint8_t)(a1 < 0 ? 0 : (a1 > 255 ? 255 : a1));
+    d[2] = (uint8_t)(a2 < 0 ? 0 : (a2 > 255 ? 255 : a2));
+}
+
+__global__ void __launch_bounds__(AUG_THREADS) aug_copy_kernel(const uint8_t* src, long long s_stride, uint8_t* dst,
+                                                               long long d_stride, int h, int w) {
+    const long long idx = (long long)blockIdx.x * AUG_THREADS + threadIdx.x;
+    if (idx >= (long long)h * w) return;
+    const int y = (int)(idx / w), x = (int)(idx - (long long)y * w);
+    const uint8_t* s = src + y * s_stride + 3 * x;
+    uint8_t* d = dst + y * d_stride + 3 * x;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply: warp -> colour jitter -> flip -> paste
+// ------------------------------------------------------------------------------------------------
+static constexpr int AUG_MAX_JOBS = 16;
+static constexpr int AUG_PIX_PER_THREAD = 4;
+struct AugJobs {
+    yolo_aug_job j[AUG_MAX_JOBS];
+};
+
+__device__ __forceinline__ long long sat_int(double v) {
+    v = rint(v);
+    v = fmin(fmax(v, -2147483648.0), 2147483647.0);
+    return (long long)v;
+}
+
+// 12-bit reciprocal tables of OpenCV's 8-bit RGB -> HSV: round((255 << 12) / i), round((180 << 12) / (6 i))
+__device__ __forceinline__ int sdiv12(int i) { return i ? (int)rint((double)(255 << 12) / (1.0 * i)) : 0; }
+__device__ __forceinline__ int hdiv12(int i) { return i ? (int)rint((double)(180 << 12) / (6.0 * i)) : 0; }
+
+__global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jobs) {
+    const yolo_aug_job& J = jobs.j[blockIdx.y];
+    __shared__ uint8_t lut[3][256];
+    __shared__ int sdiv[256], hdiv[256];
+    const long long npix = (long long)J.crop_w * J.crop_h;
+    const long long base = (long long)blockIdx.x * (AUG_THREADS * AUG_PIX_PER_THREAD);
+    if (base >= npix) return;  // whole block
+    if (J.jitter) {
+        const int t = threadIdx.x;
+        const double g[3] = {J.hue_gain, J.saturation_gain, J.exposure_gain};
+        // lut_hue = (x * gain % 180) with the sign of the divisor, the others clip(x * gain, 0, 255); both truncated
+        double h = fmod((double)t * g[0], 180.0);
+        if (h != 0.0 && h < 0.0) h += 180.0;
+        lut[0][t] = (uint8_t)(int)h;
+#pragma unroll
+        for (int c = 1; c < 3; ++c) {
+            const double v = fmin(fmax((double)t * g[c], 0.0), 255.0);
+            lut[c][t] = (uint8_t)(int)v;
+        }
+        sdiv[t] = sdiv12(t);
+        hdiv[t] = hdiv12(t);
+        __syncthreads();
+    }
+    const uint8_t* S = (const uint8_t*)J.src;
+    uint8_t* D = (uint8_t*)J.dst;
+    const int W = J.src_width, H = J.src_height;
+    for (int it = 0; it < AUG_PIX_PER_THREAD; ++it) {
+        const long long idx = base + (long long)it * AUG_THREADS + threadIdx.x;
+        if (idx >= npix) break;
+        const int py = (int)(idx / J.crop_w), px = (int)(idx - (long long)py * J.crop_w);
+        int u = J.crop_x + px, v = J.crop_y + py;
+        if (J.flip_horizontal) u = W - 1 - u;
+        if (J.flip_vertical) v = H - 1 - v;
+        int c0, c1, c2;
+        if (J.warp == 0) {
+            const uint8_t* s = S + v * J.src_stride + 3 * u;
+            c0 = s[0];
+            c1 = s[1];
+            c2 = s[2];
+        } else {
+            long long X, Y;
+            const double* m = J.inverse_map;
+            if (J.warp == 1) {
+                // 10-bit column and row terms rounded separately, half a table step added, 5 fractional bits kept
+                const long long X0 = sat_int((m[1] * (double)v + m[2]) * 1024.0) + 16;
+                const long long Y0 = sat_int((m[4] * (double)v + m[5]) * 1024.0) + 16;
+                X = (X0 + sat_int(m[0] * (double)u * 1024.0)) >> 5;
+                Y = (Y0 + sat_int(m[3] * (double)u * 1024.0)) >> 5;
+            } else {
+                // homogeneous coordinates evaluated from the first column of the pixel's 64-wide block
+                const double bx = (double)((u >> 6) << 6), x1 = (double)(u & 63), y = (double)v;
+                const double X0 = m[0] * bx + m[1] * y + m[2];
+                const double Y0 = m[3] * bx + m[4] * y + m[5];
+                const double W0 = m[6] * bx + m[7] * y + m[8];
+                double Wd = W0 + m[6] * x1;
+                Wd = Wd != 0.0 ? 32.0 / Wd : 0.0;
+                X = sat_int(fmax(-2147483648.0, fmin(2147483647.0, (X0 + m[0] * x1) * Wd)));
+                Y = sat_int(fmax(-2147483648.0, fmin(2147483647.0, (Y0 + m[3] * x1) * Wd)));
+            }
+            long long sxl = X >> 5, syl = Y >> 5;
+            sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+            syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+            const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+            const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32,
+                      w11 = fx * fy * 32;
+            const bool x0in = sx >= 0 && sx < W, x1in = sx + 1 >= 0 && sx + 1 < W;
+            const bool y0in = sy >= 0 && sy < H, y1in = sy + 1 >= 0 && sy + 1 < H;
+            const uint8_t* r0 = S + (long long)sy * J.src_stride + 3 * sx;
+            const uint8_t* r1 = r0 + J.src_stride;
+            int acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int t00 = (x0in && y0in) ? r0[c] : J.border;
+                const int t01 = (x1in && y0in) ? r0[3 + c] : J.border;
+                const int t10 = (x0in && y1in) ? r1[c] : J.border;
+                const int t11 = (x1in && y1in) ? r1[3 + c] : J.border;
+                int a = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;
+                acc[c] = a < 0 ? 0 : (a > 255 ? 255 : a);
+            }
+            c0 = acc[0];
+            c1 = acc[1];
+            c2 = acc[2];
+        }
+        if (J.jitter) {
+            const int r = J.rgb_order ? c0 : c2, g = c1, b = J.rgb_order ? c2 : c0;
+            // 8-bit RGB -> HSV (H in 0..179), integer
+            const int vmax = max(max(b, g), r), vmin = min(min(b, g), r), diff = vmax - vmin;
+            const int sat = (diff * sdiv[vmax] + (1 << 11)) >> 12;
+            int hh = vmax == r ? g - b : (vmax == g ? b - r + 2 * diff : r - g + 4 * diff);
+            hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+            hh += hh < 0 ? 180 : 0;
+            hh = hh > 255 ? 255 : hh;
+            const int h2 = lut[0][hh], s2 = lut[1][sat], v2 = lut[2][vmax];
+            // 8-bit HSV -> RGB, float
+            const float sf = (float)s2 * (1.0f / 255.0f), vf = (float)v2 * (1.0f / 255.0f);
+            float bf, gf, rf;
+            if (s2 == 0) {
+                bf = gf = rf = vf;
+            } else {
+                float hf = (float)h2 * (6.0f / 180.0f);
+                if (hf >= 6.0f) hf -= 6.0f;
+                int sector = (int)floorf(hf);
+                float fr = hf - (float)sector;
+                if ((unsigned)sector >= 6u) {
+                    sector = 0;
+                    fr = 0.f;
+                }
+                const float t0 = vf, t1 = vf * (1.f - sf), t2 = vf * (1.f - sf * fr), t3 = vf * (1.f - sf * (1.f - fr));
+                // sector -> (b, g, r) picks
+                switch (sector) {
+                    case 0: bf = t1; gf = t3; rf = t0; break;
+                    case 1: bf = t1; gf = t0; rf = t2; break;
+                    case 2: bf = t3; gf = t0; rf = t1; break;
+                    case 3: bf = t0; gf = t2; rf = t1; break;
+                    case 4: bf = t0; gf = t1; rf = t3; break;
+                    default: bf = t2; gf = t1; rf = t0; break;
+                }
+            }
+            const float bo = fminf(fmaxf(rintf(bf * 255.0f), 0.f), 255.f), go = fminf(fmaxf(rintf(gf * 255.0f), 0.f), 255.f),
+                        ro = fminf(fmaxf(rintf(rf * 255.0f), 0.f), 255.f);
+            c0 = (int)(J.rgb_order ? ro : bo);
+            c1 = (int)go;
+            c2 = (int)(J.rgb_order ? bo : ro);
+        }
+        if (J.dst_plane_stride) {
+            uint8_t* o = D + (long long)(J.dst_y + py) * J.dst_stride + (J.dst_x + px);
+            o[0] = (uint8_t)c0;
+            o[J.dst_plane_stride] = (uint8_t)c1;
+            o[2 * J.dst_plane_stride] = (uint8_t)c2;
+        } else {
+            uint8_t* o = D + (long long)(J.dst_y + py) * J.dst_stride + 3 * (J.dst_x + px);
+            o[0] = (uint8_t)c0;
+            o[1] = (uint8_t)c1;
+            o[2] = (uint8_t)c2;
+        }
+    }
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" int yolo_aug_letterbox(const void* src, int src_height, int src_width, long long src_stride, void* dst,
+                                  int dst_height, int dst_width, long long dst_stride, int top, int left,
+                                  int resized_height, int resized_width, int border_value, void* stream) {
+    YOLO_REQUIRE(src && dst, "aug_letterbox: null argument");
+    YOLO_REQUIRE(src_height > 0 && src_width > 0 && dst_height > 0 && dst_width > 0 && resized_height > 0 &&
+                     resized_width > 0,
+                 "aug_letterbox: sizes must be positive");
+    YOLO_REQUIRE(top >= 0 && left >= 0 && top + resized_height <= dst_height && left + resized_width <= dst_width,
+                 "aug_letterbox: resized %dx%d at (%d,%d) does not fit %dx%d", resized_height, resized_width, top, left,
+                 dst_height, dst_width);
+    YOLO_REQUIRE(src_stride >= 3ll * src_width && dst_stride >= 3ll * dst_width, "aug_letterbox: row stride below 3 * width");
+    YOLO_REQUIRE(border_value >= 0 && border_value <= 255, "aug_letterbox: border value %d", border_value);
+    LetterboxParams p{};
+    p.src = (const uint8_t*)src;
+    p.dst = (uint8_t*)dst;
+    p.s_stride = src_stride;
+    p.d_stride = dst_stride;
+    p.sh = src_height;
+    p.sw = src_width;
+    p.dh = dst_height;
+    p.dw = dst_width;
+    p.top = top;
+    p.left = left;
+    p.rh = resized_height;
+    p.rw = resized_width;
+    p.border = border_value;
+    p.scale_x = 1.0 / ((double)resized_width / (double)src_width);
+    p.scale_y = 1.0 / ((double)resized_height / (double)src_height);
+    const long long n = (long long)dst_height * dst_width;
+    hipLaunchKernelGGL(aug_letterbox_kernel, dim3((unsigned)((n + AUG_THREADS - 1) / AUG_THREADS)), dim3(AUG_THREADS), 0,
+                       (hipStream_t)stream, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+extern "C" size_t yolo_aug_resample_workspace_bytes(int src_height, int dst_width) {
+    return src_height > 0 && dst_width > 0 ? (size_t)src_height * dst_width * 3 : 0;
+}
+
+extern "C" int yolo_aug_resample(const void* src, int src_height, int src_width, long long src_stride, void* dst,
+                                 int dst_height, int dst_width, long long dst_stride, const int* x_bounds,
+                                 const int* x_coef, int x_ksize, const int* y_bounds, const int* y_coef, int y_ksize,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    YOLO_REQUIRE(src && dst, "aug_resample: null argument");
+    YOLO_REQUIRE(src_height > 0 && src_width > 0 && dst_height > 0 && dst_width > 0, "aug_resample: sizes must be positive");
+    YOLO_REQUIRE(src_stride >= 3ll * src_width && dst_stride >= 3ll * dst_width, "aug_resample: row stride below 3 * width");
+    const bool horiz = dst_width != src_width, vert = dst_height != src_height;
+    if (horiz) YOLO_REQUIRE(x_bounds && x_coef && x_ksize > 0, "aug_resample: horizontal tables missing");
+    if (vert) YOLO_REQUIRE(y_bounds && y_coef && y_ksize > 0, "aug_resample: vertical tables missing");
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks = [](long long n) { return dim3((unsigned)((n + AUG_THREADS - 1) / AUG_THREADS)); };
+    if (!horiz && !vert) {
+        hipLaunchKernelGGL(aug_copy_kernel, blocks((long long)dst_height * dst_width), dim3(AUG_THREADS), 0, st,
+                           (const uint8_t*)src, src_stride, (uint8_t*)dst, dst_stride, dst_height, dst_width);
+        YOLO_CHECK_HIP(hipGetLastError());
+        return YOLO_OK;
+    }
+    const uint8_t* vsrc = (const uint8_t*)src;
+    long long vstride = src_stride;
+    if (horiz) {
+        ResampleParams p{};
+        p.src = (const uint8_t*)src;
+        p.s_stride = src_stride;
+        p.out_h = src_height;
+        p.out_w = dst_width;
+        p.bounds = x_bounds;
+        p.coef = x_coef;
+        p.ksize = x_ksize;
+        if (vert) {
+            YOLO_REQUIRE(workspace && workspace_bytes >= yolo_aug_resample_workspace_bytes(src_height, dst_width),
+                         "aug_resample: workspace of %zu bytes is too small", workspace_bytes);
+            p.dst = (uint8_t*)workspace;
+            p.d_stride = 3ll * dst_width;
+            vsrc = p.dst;
+            vstride = p.d_stride;
+        } else {
+            p.dst = (uint8_t*)dst;
+            p.d_stride = dst_stride;
+        }
+        hipLaunchKernelGGL(aug_resample_kernel<true>, blocks((long long)p.out_h * p.out_w), dim3(AUG_THREADS), 0, st, p);
+        YOLO_CHECK_HIP(hipGetLastError());
+    }
+    if (vert) {
+        ResampleParams p{};
+        p.src = vsrc;
+        p.s_stride = vstride;
+        p.dst = (uint8_t*)dst;
+        p.d_stride = dst_stride;
+        p.out_h = dst_height;
+        p.out_w = dst_width;
+        p.bounds = y_bounds;
+        p.coef = y_coef;
+        p.ksize = y_ksize;
+        hipLaunchKernelGGL(aug_resample_kernel<false>, blocks((long long)p.out_h * p.out_w), dim3(AUG_THREADS), 0, st, p);
+        YOLO_CHECK_HIP(hipGetLastError());
+    }
+    return YOLO_OK;
+}
+
+extern "C" int yolo_aug_apply(const yolo_aug_job* jobs, int n_jobs, void* stream) {
+    YOLO_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), "aug_apply: null argument");
+    for (int i = 0; i < n_jobs; ++i) {
+        const yolo_aug_job& j = jobs[i];
+        YOLO_REQUIRE(j.src && j.dst, "aug_apply: job %d: null image", i);
+        YOLO_REQUIRE(j.src_height > 0 && j.src_width > 0 && j.src_stride >= 3ll * j.src_width, "aug_apply: job %d: bad source geometry", i);
+        YOLO_REQUIRE(j.crop_w >= 0 && j.crop_h >= 0 && j.crop_x >= 0 && j.crop_y >= 0 && j.crop_x + j.crop_w <= j.src_width &&
+                         j.crop_y + j.crop_h <= j.src_height,
+                     "aug_apply: job %d: crop [%d,%d)+(%d,%d) outside the %dx%d image", i, j.crop_x, j.crop_y, j.crop_w, j.crop_h,
+                     j.src_width, j.src_height);
+        YOLO_REQUIRE(j.dst_x >= 0 && j.dst_y >= 0 && j.dst_x + j.crop_w <= j.dst_width && j.dst_y + j.crop_h <= j.dst_height &&
+                         (j.dst_plane_stride ? j.dst_stride >= (long long)j.dst_width &&
+                                                   j.dst_plane_stride >= j.dst_stride * j.dst_height
+                                             : j.dst_stride >= 3ll * j.dst_width),
+                     "aug_apply: job %d: paste at (%d,%d) of %dx%d outside the %dx%d canvas", i, j.dst_x, j.dst_y, j.crop_w,
+                     j.crop_h, j.dst_width, j.dst_height);
+        YOLO_REQUIRE(j.warp >= 0 && j.warp <= 2, "aug_apply: job %d: warp mode %d", i, j.warp);
+        YOLO_REQUIRE(j.border >= 0 && j.border <= 255, "aug_apply: job %d: border value %d", i, j.border);
+    }
+    for (int first = 0; first < n_jobs; first += AUG_MAX_JOBS) {
+        const int n = n_jobs - first < AUG_MAX_JOBS ? n_jobs - first : AUG_MAX_JOBS;
+        AugJobs batch{};
+        long long most = 0;
+        for (int i = 0; i < n; ++i) {
+            batch.j[i] = jobs[first + i];
+            const long long np = (long long)batch.j[i].crop_w * batch.j[i].crop_h;
+            most = np > most ? np : most;
+        }
+        if (most == 0) continue;
+        const int per_block = AUG_THREADS * AUG_PIX_PER_THREAD;
+        hipLaunchKernelGGL(aug_apply_kernel, dim3((unsigned)((most + per_block - 1) / per_block), n), dim3(AUG_THREADS), 0,
+                           (hipStream_t)stream, batch);
+        YOLO_CHECK_HIP(hipGetLastError());
+    }
+    return YOLO_OK;
+}

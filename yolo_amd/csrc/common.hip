@@ -19,4 +19,4 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace yolo
 
 extern "C" const char* yolo_last_error(void) { return yolo::last_error_buf(); }
-extern "C" int yolo_abi_version(void) { return 5; }
+extern "C" int yolo_abi_version(void) { return 6; }

@@ -6,6 +6,7 @@ to a hand-written gfx950 kernel.  There is no fallback: without the library or a
 from __future__ import annotations
 
 import ctypes
+import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -565,3 +566,133 @@ def conv3x3s2_dgrad(dz: View, w_dgrad: torch.Tensor, bias: torch.Tensor, dx: Vie
     check(lib().yolo_conv3x3s2_dgrad(ctypes.byref(zv), _ptr(w_dgrad), _ptr(bias), ctypes.byref(rv) if rv is not None else None,
                                      ctypes.byref(xv), dz.N, cin, cout, dtype_code(dz.buf.dtype), _stream()),
           "yolo_conv3x3s2_dgrad")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training-image augmentation (uint8 HWC images on the device)
+# ---------------------------------------------------------------------------------------------------------
+def _check_image(t: torch.Tensor, what: str) -> None:
+    _require_cuda(t, what)
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3 or t.stride(2) != 1 or t.stride(1) != 3:
+        raise ValueError(f"{what}: expected a uint8 [H, W, 3] tensor with packed pixels, got {t.dtype} "
+                         f"{tuple(t.shape)} strides {tuple(t.stride())}")
+
+
+def aug_letterbox(src: torch.Tensor, out_hw: Tuple[int, int], top: int, left: int, resized_hw: Tuple[int, int],
+                  border: int = 114, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cv2-style linear resize of ``src`` to ``resized_hw`` placed at (top, left) of an ``out_hw`` image of ``border``."""
+    _check_image(src, "aug_letterbox")
+    if out is None:
+        out = torch.empty((out_hw[0], out_hw[1], 3), dtype=torch.uint8, device=src.device)
+    _check_image(out, "aug_letterbox")
+    check(lib().yolo_aug_letterbox(_ptr(src), src.shape[0], src.shape[1], src.stride(0), _ptr(out), out.shape[0],
+                                   out.shape[1], out.stride(0), top, left, resized_hw[0], resized_hw[1], border, _stream()),
+          "yolo_aug_letterbox")
+    return out
+
+
+_RESAMPLE_TABLES = {}
+
+
+def resample_tables(in_size: int, out_size: int, device) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """Device tables of one Pillow-style bilinear pass (first source index + count, 22-bit coefficients) for an axis
+    going from ``in_size`` to ``out_size``; cached per (sizes, device)."""
+    key = (in_size, out_size, str(device))
+    hit = _RESAMPLE_TABLES.get(key)
+    if hit is None:
+        import numpy as np
+        scale = in_size / out_size
+        filterscale = max(scale, 1.0)
+        support = 1.0 * filterscale
+        ksize = int(math.ceil(support)) * 2 + 1
+        xx = np.arange(out_size, dtype=np.float64)
+        center = (xx + 0.5) * scale
+        xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)
+        xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size)
+        cnt = xmax - xmin
+        k = np.arange(ksize, dtype=np.float64)[None, :]
+        t = np.abs((k + xmin[:, None] - center[:, None] + 0.5) * (1.0 / filterscale))
+        w = np.where((t < 1.0) & (k < cnt[:, None]), 1.0 - t, 0.0)
+        # Pillow sums the weights left to right; numpy's pairwise sum may differ in the last bit, so accumulate alike
+        ww = np.zeros(out_size)
+        for i in range(ksize):
+            ww = ww + w[:, i]
+        w = np.where(ww[:, None] != 0.0, w / np.where(ww[:, None] != 0.0, ww[:, None], 1.0), w)
+        coef = (w * float(1 << 22) + 0.5).astype(np.int64).astype(np.int32)  # weights are >= 0: truncation = Pillow's rounding
+        bounds = np.stack([xmin, cnt], 1).astype(np.int32)
+        hit = (torch.from_numpy(bounds).to(device), torch.from_numpy(np.ascontiguousarray(coef)).to(device), ksize)
+        _RESAMPLE_TABLES[key] = hit
+    return hit
+
+
+def aug_resample(src: torch.Tensor, out_hw: Tuple[int, int], out: Optional[torch.Tensor] = None,
+                 workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Pillow ``Image.resize((w, h), BILINEAR)`` of a uint8 HWC device image."""
+    _check_image(src, "aug_resample")
+    H, W = src.shape[0], src.shape[1]
+    nh, nw = out_hw
+    if out is None:
+        out = torch.empty((nh, nw, 3), dtype=torch.uint8, device=src.device)
+    _check_image(out, "aug_resample")
+    xb = xc = yb = yc = None
+    xk = yk = 0
+    if nw != W:
+        xb, xc, xk = resample_tables(W, nw, src.device)
+    if nh != H:
+        yb, yc, yk = resample_tables(H, nh, src.device)
+    need = int(lib().yolo_aug_resample_workspace_bytes(H, nw)) if (nw != W and nh != H) else 0
+    if need and (workspace is None or workspace.numel() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=src.device)
+    check(lib().yolo_aug_resample(_ptr(src), H, W, src.stride(0), _ptr(out), nh, nw, out.stride(0), _ptr(xb), _ptr(xc), xk,
+                                  _ptr(yb), _ptr(yc), yk, _ptr(workspace) if need else None,
+                                  workspace.numel() if need else 0, _stream()),
+          "yolo_aug_resample")
+    return out
+
+
+def aug_job(src: torch.Tensor, dst: torch.Tensor, *, dst_xy: Tuple[int, int] = (0, 0),
+            crop: Optional[Tuple[int, int, int, int]] = None, inverse_map=None, perspective: bool = False,
+            jitter: Optional[Tuple[float, float, float]] = None, rgb: bool = False, flip_horizontal: bool = False,
+            flip_vertical: bool = False, border: int = 114, planar: bool = False) -> "_lib.AugJob":
+    """One image's fused warp -> colour jitter -> flip -> paste.  ``inverse_map``: 6 (affine) or 9 (perspective)
+    doubles taking output pixels to source pixels; ``crop`` = (x, y, w, h) of the augmented image (default: all);
+    ``dst_xy``: where the crop lands in ``dst``; ``planar``: ``dst`` is a [3, H, W] tensor (the model's input layout)
+    instead of [H, W, 3].  The job holds raw pointers: keep ``src`` / ``dst`` alive."""
+    _check_image(src, "aug_job")
+    j = _lib.AugJob()
+    j.src, j.dst = src.data_ptr(), dst.data_ptr()
+    if planar:
+        _require_cuda(dst, "aug_job")
+        if dst.dtype != torch.uint8 or dst.dim() != 3 or dst.shape[0] != 3 or dst.stride(2) != 1:
+            raise ValueError(f"aug_job: planar destination must be uint8 [3, H, W], got {dst.dtype} {tuple(dst.shape)}")
+        j.src_stride, j.dst_stride, j.dst_plane_stride = src.stride(0), dst.stride(1), dst.stride(0)
+        j.dst_height, j.dst_width = dst.shape[1], dst.shape[2]
+    else:
+        _check_image(dst, "aug_job")
+        j.src_stride, j.dst_stride = src.stride(0), dst.stride(0)
+        j.dst_height, j.dst_width = dst.shape[0], dst.shape[1]
+    j.src_height, j.src_width = src.shape[0], src.shape[1]
+    cx, cy, cw, ch = crop if crop is not None else (0, 0, src.shape[1], src.shape[0])
+    j.dst_x, j.dst_y, j.crop_x, j.crop_y, j.crop_w, j.crop_h = dst_xy[0], dst_xy[1], cx, cy, cw, ch
+    if inverse_map is not None:
+        m = [float(v) for v in inverse_map]
+        if len(m) != (9 if perspective else 6):
+            raise ValueError(f"aug_job: inverse_map has {len(m)} values")
+        j.warp = 2 if perspective else 1
+        for i, v in enumerate(m):
+            j.inverse_map[i] = v
+    if jitter is not None:
+        j.jitter = 1
+        j.hue_gain, j.saturation_gain, j.exposure_gain = (float(v) for v in jitter)
+    j.rgb_order = int(rgb)
+    j.flip_horizontal, j.flip_vertical, j.border = int(flip_horizontal), int(flip_vertical), border
+    return j
+
+
+def aug_apply(jobs: Sequence["_lib.AugJob"]) -> None:
+    """Run the jobs (16 images per launch)."""
+    n = len(jobs)
+    if n == 0:
+        return
+    arr = (_lib.AugJob * n)(*jobs)
+    check(lib().yolo_aug_apply(ctypes.cast(arr, ctypes.c_void_p), n, _stream()), "yolo_aug_apply")
