@@ -371,6 +371,18 @@ int yolo_aug_resample(const void* src, int src_height, int src_width, long long 
                       int x_ksize, const int* y_bounds, const int* y_coef, int y_ksize, void* workspace,
                       size_t workspace_bytes, void* stream);
 size_t yolo_aug_resample_workspace_bytes(int src_height, int dst_width);
+/* The same for many images: 16 per launch, all horizontal passes first, then all vertical ones.  jobs: HOST array.
+ * Every job that changes both sizes needs its own workspace (the jobs of a call run concurrently). */
+typedef struct yolo_aug_resample_job {
+    const void* src;
+    void* dst;
+    void* workspace;
+    long long workspace_bytes, src_stride, dst_stride;
+    int src_height, src_width, dst_height, dst_width;
+    const int *x_bounds, *x_coef, *y_bounds, *y_coef;
+    int x_ksize, y_ksize;
+} yolo_aug_resample_job;
+int yolo_aug_resample_batch(const yolo_aug_resample_job* jobs, int n_jobs, void* stream);
 
 /*
  * One image's remaining augmentation as ONE pass: AffineTransform.apply_image (transforms.py:43-50: cv2.warpAffine /
@@ -383,6 +395,8 @@ size_t yolo_aug_resample_workspace_bytes(int src_height, int dst_width);
  *                pixels to source pixels, i.e. it is the INVERSE of AffineTransform.M
  *   jitter       0 / 1; hue_gain, saturation_gain, exposure_gain as ColorJitterTransform's arguments
  *   rgb_order    1 if channel 0 is red (INPUT.FORMAT "RGB"), 0 for BGR
+ *   reverse_channels  1: write the three channels in reverse order (a BGR source delivered as RGB: the reference
+ *                flips the decoded image on the host, yolo/data/detection_utils.py:13-14); rgb_order describes src
  *   dst_plane_stride  0: dst is HWC like the source (dst_stride >= 3 * dst_width); otherwise dst is CHW -- the
  *                layout the model's batched_inputs carry (dataset_mapper.py:132) -- with planes this many bytes
  *                apart and rows dst_stride >= dst_width bytes apart
@@ -393,7 +407,7 @@ typedef struct yolo_aug_job {
     long long src_stride, dst_stride, dst_plane_stride;
     int src_height, src_width, dst_height, dst_width;
     int dst_x, dst_y, crop_x, crop_y, crop_w, crop_h;
-    int warp, jitter, rgb_order, flip_horizontal, flip_vertical, border;
+    int warp, jitter, rgb_order, flip_horizontal, flip_vertical, border, reverse_channels, reserved;
     double inverse_map[9];
     double hue_gain, saturation_gain, exposure_gain;
 } yolo_aug_job;

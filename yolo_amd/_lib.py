@@ -26,6 +26,16 @@ _VP = ctypes.POINTER(YoloView)
 _IP = ctypes.POINTER(c_int)
 _FP = ctypes.POINTER(c_float)
 
+class AugResampleJob(ctypes.Structure):
+    """``yolo_aug_resample_job`` of include/yolo_hip.h."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("workspace_bytes", ctypes.c_longlong), ("src_stride", ctypes.c_longlong), ("dst_stride", ctypes.c_longlong),
+                ("src_height", ctypes.c_int), ("src_width", ctypes.c_int), ("dst_height", ctypes.c_int),
+                ("dst_width", ctypes.c_int),
+                ("x_bounds", ctypes.c_void_p), ("x_coef", ctypes.c_void_p), ("y_bounds", ctypes.c_void_p),
+                ("y_coef", ctypes.c_void_p), ("x_ksize", ctypes.c_int), ("y_ksize", ctypes.c_int)]
+
+
 class AugJob(ctypes.Structure):
     """``yolo_aug_job`` of include/yolo_hip.h."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
@@ -37,6 +47,7 @@ class AugJob(ctypes.Structure):
                 ("crop_w", ctypes.c_int), ("crop_h", ctypes.c_int),
                 ("warp", ctypes.c_int), ("jitter", ctypes.c_int), ("rgb_order", ctypes.c_int),
                 ("flip_horizontal", ctypes.c_int), ("flip_vertical", ctypes.c_int), ("border", ctypes.c_int),
+                ("reverse_channels", ctypes.c_int), ("reserved", ctypes.c_int),
                 ("inverse_map", ctypes.c_double * 9),
                 ("hue_gain", ctypes.c_double), ("saturation_gain", ctypes.c_double), ("exposure_gain", ctypes.c_double)]
 
@@ -82,6 +93,7 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "yolo_aug_resample_workspace_bytes": (c_size_t, [c_int, c_int]),
     "yolo_aug_apply": (c_int, [c_void_p, c_int, c_void_p]),
+    "yolo_aug_resample_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "yolo_conv3x3s2_dgrad": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,

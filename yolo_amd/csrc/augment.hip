@@ -79,55 +79,90 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_letterbox_kernel(const Letter
 }
 
 // ------------------------------------------------------------------------------------------------
-// resample: out[o] = clip8((2^21 + sum_k in[first(o) + k] * coef[o][k]) >> 22) along one axis
+// resample: out[o] = clip8((2^21 + sum_k in[first(o) + k] * coef[o][k]) >> 22) along one axis; up to 16 images per launch
 // ------------------------------------------------------------------------------------------------
-struct ResampleParams {
+struct PassJob {
     const uint8_t* src;
     uint8_t* dst;
     long long s_stride, d_stride;
-    int out_h, out_w;  // of this pass
+    int out_h, out_w;   // of this pass
     const int* bounds;  // [n_out][2]: first source index, count
     const int* coef;    // [n_out][ksize]
     int ksize;
+    int mode;  // 0 horizontal, 1 vertical, 2 copy
+};
+static constexpr int AUG_MAX_PASS_JOBS = 16;
+struct PassJobs {
+    PassJob j[AUG_MAX_PASS_JOBS];
 };
 
-template <bool HORIZONTAL>
-__global__ void __launch_bounds__(AUG_THREADS) aug_resample_kernel(const ResampleParams p) {
-    const long long idx = (long long)blockIdx.x * AUG_THREADS + threadIdx.x;
-    if (idx >= (long long)p.out_h * p.out_w) return;
-    const int y = (int)(idx / p.out_w), x = (int)(idx - (long long)y * p.out_w);
-    const int o = HORIZONTAL ? x : y;
-    const int first = p.bounds[2 * o], n = p.bounds[2 * o + 1];
-    const int* k = p.coef + (long long)o * p.ksize;
-    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
-    const uint8_t* s = HORIZONTAL ? p.src + y * p.s_stride + 3 * first : p.src + first * p.s_stride + 3 * x;
-    const long long step = HORIZONTAL ? 3 : p.s_stride;
-    for (int i = 0; i < n; ++i) {
-        const int w = k[i];
-        a0 += s[0] * w;
-        a1 += s[1] * w;
-        a2 += s[2] * w;
-        s += step;
-    }
-    uint8_t* d = p.dst + y * p.d_stride + 3 * x;
-    a0 >>= 22;
-    a1 >>= 22;
-    a2 >>= 22;
-    d[0] = (uint8_t)(a0 < 0 ? 0 : (a0 > 255 ? 255 : a0));
-    d[1] = (uint8_t)(a1 < 0 ? 0 : (a1 > 255 ? 255 : a1));
-    d[2] = (uint8_t)(a2 < 0 ? 0 : (a2 > 255 ? 255 : a2));
+__device__ __forceinline__ uint8_t clip8(int a) {
+    a >>= 22;
+    return (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
 }
 
-__global__ void __launch_bounds__(AUG_THREADS) aug_copy_kernel(const uint8_t* src, long long s_stride, uint8_t* dst,
-                                                               long long d_stride, int h, int w) {
+__global__ void __launch_bounds__(AUG_THREADS) aug_resample_kernel(const PassJobs jobs) {
+    const PassJob& p = jobs.j[blockIdx.y];
     const long long idx = (long long)blockIdx.x * AUG_THREADS + threadIdx.x;
-    if (idx >= (long long)h * w) return;
-    const int y = (int)(idx / w), x = (int)(idx - (long long)y * w);
-    const uint8_t* s = src + y * s_stride + 3 * x;
-    uint8_t* d = dst + y * d_stride + 3 * x;
-    d[0] = s[0];
-    d[1] = s[1];
-    d[2] = s[2];
+    if (p.mode == 0) {
+        // one output pixel per thread
+        if (idx >= (long long)p.out_h * p.out_w) return;
+        const int y = (int)(idx / p.out_w), x = (int)(idx - (long long)y * p.out_w);
+        const int first = p.bounds[2 * x], n = p.bounds[2 * x + 1];
+        const int* k = p.coef + (long long)x * p.ksize;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        const uint8_t* s = p.src + y * p.s_stride + 3 * first;
+        for (int i = 0; i < n; ++i) {
+            const int w = k[i];
+            a0 += s[0] * w;
+            a1 += s[1] * w;
+            a2 += s[2] * w;
+            s += 3;
+        }
+        uint8_t* d = p.dst + y * p.d_stride + 3 * x;
+        d[0] = clip8(a0);
+        d[1] = clip8(a1);
+        d[2] = clip8(a2);
+    } else {
+        // four consecutive bytes of an output row per thread: the taps are whole rows, read 4 bytes at a time
+        const int row_bytes = 3 * p.out_w, quads = (row_bytes + 3) >> 2;
+        if (idx >= (long long)p.out_h * quads) return;
+        const int y = (int)(idx / quads), b = (int)(idx - (long long)y * quads) * 4;
+        const int nb = row_bytes - b < 4 ? row_bytes - b : 4;
+        int first = y, n = 1;
+        const int* k = nullptr;
+        if (p.mode == 1) {
+            first = p.bounds[2 * y];
+            n = p.bounds[2 * y + 1];
+            k = p.coef + (long long)y * p.ksize;
+        }
+        int a[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+        const uint8_t* s = p.src + first * p.s_stride + b;
+        for (int i = 0; i < n; ++i) {
+            const int w = k ? k[i] : (1 << 22);
+            uint32_t v = 0;
+            if (nb == 4) {
+                __builtin_memcpy(&v, s, 4);
+            } else {
+                for (int e = 0; e < nb; ++e) v |= (uint32_t)s[e] << (8 * e);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += (int)((v >> (8 * e)) & 255u) * w;
+            s += p.s_stride;
+        }
+        uint8_t* d = p.dst + y * p.d_stride + b;
+        if (p.mode == 2) {  // copy: the accumulators hold 2^21 + v * 2^22
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] -= 1 << 21;
+        }
+        const uint32_t o = (uint32_t)clip8(a[0]) | ((uint32_t)clip8(a[1]) << 8) | ((uint32_t)clip8(a[2]) << 16) |
+                           ((uint32_t)clip8(a[3]) << 24);
+        if (nb == 4) {
+            __builtin_memcpy(d, &o, 4);
+        } else {
+            for (int e = 0; e < nb; ++e) d[e] = (uint8_t)(o >> (8 * e));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,19 +249,32 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jo
             const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
             const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32,
                       w11 = fx * fy * 32;
-            const bool x0in = sx >= 0 && sx < W, x1in = sx + 1 >= 0 && sx + 1 < W;
-            const bool y0in = sy >= 0 && sy < H, y1in = sy + 1 >= 0 && sy + 1 < H;
-            const uint8_t* r0 = S + (long long)sy * J.src_stride + 3 * sx;
-            const uint8_t* r1 = r0 + J.src_stride;
             int acc[3];
+            if (sx >= 0 && sy >= 0 && sx + 3 <= W && sy + 1 < H) {
+                // whole 2 x 2 patch inside and 8 readable bytes in both rows: two (unaligned) 8-byte loads
+                const uint8_t* r0 = S + (long long)sy * J.src_stride + 3 * sx;
+                uint64_t q0, q1;
+                __builtin_memcpy(&q0, r0, 8);
+                __builtin_memcpy(&q1, r0 + J.src_stride, 8);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int t00 = (x0in && y0in) ? r0[c] : J.border;
-                const int t01 = (x1in && y0in) ? r0[3 + c] : J.border;
-                const int t10 = (x0in && y1in) ? r1[c] : J.border;
-                const int t11 = (x1in && y1in) ? r1[3 + c] : J.border;
-                int a = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;
-                acc[c] = a < 0 ? 0 : (a > 255 ? 255 : a);
+                for (int c = 0; c < 3; ++c) {
+                    const int t00 = (int)((q0 >> (8 * c)) & 255u), t01 = (int)((q0 >> (8 * (c + 3))) & 255u);
+                    const int t10 = (int)((q1 >> (8 * c)) & 255u), t11 = (int)((q1 >> (8 * (c + 3))) & 255u);
+                    acc[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;
+                }
+            } else {
+                const bool x0in = sx >= 0 && sx < W, x1in = sx + 1 >= 0 && sx + 1 < W;
+                const bool y0in = sy >= 0 && sy < H, y1in = sy + 1 >= 0 && sy + 1 < H;
+                const uint8_t* r0 = S + (long long)sy * J.src_stride + 3 * sx;
+                const uint8_t* r1 = r0 + J.src_stride;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int t00 = (x0in && y0in) ? r0[c] : J.border;
+                    const int t01 = (x1in && y0in) ? r0[3 + c] : J.border;
+                    const int t10 = (x0in && y1in) ? r1[c] : J.border;
+                    const int t11 = (x1in && y1in) ? r1[3 + c] : J.border;
+                    acc[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;
+                }
             }
             c0 = acc[0];
             c1 = acc[1];
@@ -272,6 +320,11 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jo
             c0 = (int)(J.rgb_order ? ro : bo);
             c1 = (int)go;
             c2 = (int)(J.rgb_order ? bo : ro);
+        }
+        if (J.reverse_channels) {
+            const int t = c0;
+            c0 = c2;
+            c2 = t;
         }
         if (J.dst_plane_stride) {
             uint8_t* o = D + (long long)(J.dst_y + py) * J.dst_stride + (J.dst_x + px);
@@ -330,64 +383,114 @@ extern "C" size_t yolo_aug_resample_workspace_bytes(int src_height, int dst_widt
     return src_height > 0 && dst_width > 0 ? (size_t)src_height * dst_width * 3 : 0;
 }
 
+static int launch_passes(const PassJob* jobs, int n, hipStream_t st) {
+    for (int first = 0; first < n; first += AUG_MAX_PASS_JOBS) {
+        const int m = n - first < AUG_MAX_PASS_JOBS ? n - first : AUG_MAX_PASS_JOBS;
+        PassJobs batch{};
+        long long most = 0;
+        for (int i = 0; i < m; ++i) {
+            batch.j[i] = jobs[first + i];
+            const PassJob& p = batch.j[i];
+            const long long work = p.mode == 0 ? (long long)p.out_h * p.out_w : (long long)p.out_h * ((3 * p.out_w + 3) >> 2);
+            most = work > most ? work : most;
+        }
+        hipLaunchKernelGGL(aug_resample_kernel, dim3((unsigned)((most + AUG_THREADS - 1) / AUG_THREADS), m),
+                           dim3(AUG_THREADS), 0, st, batch);
+        YOLO_CHECK_HIP(hipGetLastError());
+    }
+    return YOLO_OK;
+}
+
+extern "C" int yolo_aug_resample_batch(const yolo_aug_resample_job* jobs, int n_jobs, void* stream) {
+    YOLO_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), "aug_resample: null argument");
+    // first the horizontal passes (and plain copies) of all images, then the vertical ones
+    PassJob* pass1 = n_jobs ? new PassJob[n_jobs] : nullptr;
+    PassJob* pass2 = n_jobs ? new PassJob[n_jobs] : nullptr;
+    int n1 = 0, n2 = 0, rc = YOLO_OK;
+    for (int i = 0; i < n_jobs && rc == YOLO_OK; ++i) {
+        const yolo_aug_resample_job& j = jobs[i];
+        const bool horiz = j.dst_width != j.src_width, vert = j.dst_height != j.src_height;
+        if (!(j.src && j.dst))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: null image", i);
+        else if (!(j.src_height > 0 && j.src_width > 0 && j.dst_height > 0 && j.dst_width > 0))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: sizes must be positive", i);
+        else if (!(j.src_stride >= 3ll * j.src_width && j.dst_stride >= 3ll * j.dst_width))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: row stride below 3 * width", i);
+        else if (horiz && !(j.x_bounds && j.x_coef && j.x_ksize > 0))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: horizontal tables missing", i);
+        else if (vert && !(j.y_bounds && j.y_coef && j.y_ksize > 0))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: vertical tables missing", i);
+        else if (horiz && vert &&
+                 !(j.workspace && j.workspace_bytes >= yolo_aug_resample_workspace_bytes(j.src_height, j.dst_width)))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: workspace of %zu bytes is too small", i, (size_t)j.workspace_bytes);
+        if (rc != YOLO_OK) break;
+        const uint8_t* vsrc = (const uint8_t*)j.src;
+        long long vstride = j.src_stride;
+        if (horiz || !vert) {
+            PassJob p{};
+            p.src = (const uint8_t*)j.src;
+            p.s_stride = j.src_stride;
+            p.out_h = j.src_height;
+            p.out_w = j.dst_width;
+            p.mode = horiz ? 0 : 2;
+            p.bounds = j.x_bounds;
+            p.coef = j.x_coef;
+            p.ksize = j.x_ksize;
+            if (horiz && vert) {
+                p.dst = (uint8_t*)j.workspace;
+                p.d_stride = 3ll * j.dst_width;
+                vsrc = p.dst;
+                vstride = p.d_stride;
+            } else {
+                p.dst = (uint8_t*)j.dst;
+                p.d_stride = j.dst_stride;
+            }
+            pass1[n1++] = p;
+        }
+        if (vert) {
+            PassJob p{};
+            p.src = vsrc;
+            p.s_stride = vstride;
+            p.dst = (uint8_t*)j.dst;
+            p.d_stride = j.dst_stride;
+            p.out_h = j.dst_height;
+            p.out_w = j.dst_width;
+            p.mode = 1;
+            p.bounds = j.y_bounds;
+            p.coef = j.y_coef;
+            p.ksize = j.y_ksize;
+            pass2[n2++] = p;
+        }
+    }
+    if (rc == YOLO_OK) rc = launch_passes(pass1, n1, (hipStream_t)stream);
+    if (rc == YOLO_OK) rc = launch_passes(pass2, n2, (hipStream_t)stream);
+    delete[] pass1;
+    delete[] pass2;
+    return rc;
+}
+
 extern "C" int yolo_aug_resample(const void* src, int src_height, int src_width, long long src_stride, void* dst,
                                  int dst_height, int dst_width, long long dst_stride, const int* x_bounds,
                                  const int* x_coef, int x_ksize, const int* y_bounds, const int* y_coef, int y_ksize,
                                  void* workspace, size_t workspace_bytes, void* stream) {
-    YOLO_REQUIRE(src && dst, "aug_resample: null argument");
-    YOLO_REQUIRE(src_height > 0 && src_width > 0 && dst_height > 0 && dst_width > 0, "aug_resample: sizes must be positive");
-    YOLO_REQUIRE(src_stride >= 3ll * src_width && dst_stride >= 3ll * dst_width, "aug_resample: row stride below 3 * width");
-    const bool horiz = dst_width != src_width, vert = dst_height != src_height;
-    if (horiz) YOLO_REQUIRE(x_bounds && x_coef && x_ksize > 0, "aug_resample: horizontal tables missing");
-    if (vert) YOLO_REQUIRE(y_bounds && y_coef && y_ksize > 0, "aug_resample: vertical tables missing");
-    hipStream_t st = (hipStream_t)stream;
-    auto blocks = [](long long n) { return dim3((unsigned)((n + AUG_THREADS - 1) / AUG_THREADS)); };
-    if (!horiz && !vert) {
-        hipLaunchKernelGGL(aug_copy_kernel, blocks((long long)dst_height * dst_width), dim3(AUG_THREADS), 0, st,
-                           (const uint8_t*)src, src_stride, (uint8_t*)dst, dst_stride, dst_height, dst_width);
-        YOLO_CHECK_HIP(hipGetLastError());
-        return YOLO_OK;
-    }
-    const uint8_t* vsrc = (const uint8_t*)src;
-    long long vstride = src_stride;
-    if (horiz) {
-        ResampleParams p{};
-        p.src = (const uint8_t*)src;
-        p.s_stride = src_stride;
-        p.out_h = src_height;
-        p.out_w = dst_width;
-        p.bounds = x_bounds;
-        p.coef = x_coef;
-        p.ksize = x_ksize;
-        if (vert) {
-            YOLO_REQUIRE(workspace && workspace_bytes >= yolo_aug_resample_workspace_bytes(src_height, dst_width),
-                         "aug_resample: workspace of %zu bytes is too small", workspace_bytes);
-            p.dst = (uint8_t*)workspace;
-            p.d_stride = 3ll * dst_width;
-            vsrc = p.dst;
-            vstride = p.d_stride;
-        } else {
-            p.dst = (uint8_t*)dst;
-            p.d_stride = dst_stride;
-        }
-        hipLaunchKernelGGL(aug_resample_kernel<true>, blocks((long long)p.out_h * p.out_w), dim3(AUG_THREADS), 0, st, p);
-        YOLO_CHECK_HIP(hipGetLastError());
-    }
-    if (vert) {
-        ResampleParams p{};
-        p.src = vsrc;
-        p.s_stride = vstride;
-        p.dst = (uint8_t*)dst;
-        p.d_stride = dst_stride;
-        p.out_h = dst_height;
-        p.out_w = dst_width;
-        p.bounds = y_bounds;
-        p.coef = y_coef;
-        p.ksize = y_ksize;
-        hipLaunchKernelGGL(aug_resample_kernel<false>, blocks((long long)p.out_h * p.out_w), dim3(AUG_THREADS), 0, st, p);
-        YOLO_CHECK_HIP(hipGetLastError());
-    }
-    return YOLO_OK;
+    yolo_aug_resample_job j{};
+    j.src = src;
+    j.dst = dst;
+    j.workspace = workspace;
+    j.workspace_bytes = (long long)workspace_bytes;
+    j.src_stride = src_stride;
+    j.dst_stride = dst_stride;
+    j.src_height = src_height;
+    j.src_width = src_width;
+    j.dst_height = dst_height;
+    j.dst_width = dst_width;
+    j.x_bounds = x_bounds;
+    j.x_coef = x_coef;
+    j.y_bounds = y_bounds;
+    j.y_coef = y_coef;
+    j.x_ksize = x_ksize;
+    j.y_ksize = y_ksize;
+    return yolo_aug_resample_batch(&j, 1, stream);
 }
 
 extern "C" int yolo_aug_apply(const yolo_aug_job* jobs, int n_jobs, void* stream) {

@@ -23,7 +23,7 @@ import torch
 
 from ..structures import Boxes, Instances
 from .augmentation_impl import Augmentation, AugmentationList
-from .detection_utils import build_augmentation, read_image
+from .detection_utils import build_augmentation, read_bgr
 from .transforms import (BORDER_VALUE, LetterBoxTransform, ResizeTransform, Transform, TransformList, as_device_image,
                          fused_job)
 from .. import ops
@@ -31,6 +31,12 @@ from .. import ops
 __all__ = ["YOLOV3DatasetMapper"]
 
 XYXY_ABS, XYWH_ABS = 0, 1
+
+
+def _copy_dict(d: dict) -> dict:
+    """``copy.deepcopy(dataset_dict)`` (dataset_mapper.py:87,99,114) that shares an in-memory image array, which
+    nothing here writes to."""
+    return {k: (v if k == "image" else copy.deepcopy(v)) for k, v in d.items()}
 
 
 class _Planned:
@@ -65,6 +71,7 @@ class YOLOV3DatasetMapper:
         self.device = torch.device(device)
         mode = "training" if is_train else "inference"
         logging.getLogger(__name__).info(f"[DatasetMapper] Augmentations used in {mode}: {augmentations}")
+        self._resizes: list = []
         self.mosaic_transform = mosaic_transform
         if self.mosaic_transform.ENABLE:
             self.mosaic_pool = deque(maxlen=self.mosaic_transform.POOL_CAPACITY)
@@ -80,16 +87,16 @@ class YOLOV3DatasetMapper:
 
     # ------------------------------------------------------------------------------------------
     def _plan(self, dataset_dict: dict, jobs: list, keep: list) -> dict:
-        """Everything of ``__call__`` except launching the fused pass: appends this image's jobs to ``jobs`` (and the
-        tensors they point into to ``keep``) and returns the output dict."""
-        dataset_dict = copy.deepcopy(dataset_dict)
+        """Everything of ``__call__`` except the launches: appends this image's fused-pass jobs to ``jobs``, the
+        tensors they point into to ``keep`` and its pending resizes to ``self._resizes``; returns the output dict."""
+        dataset_dict = _copy_dict(dataset_dict)
         mosaic_samples = None
         if self.mosaic_transform.ENABLE and self.is_train:
             if len(self.mosaic_pool) > self.mosaic_transform.NUM_IMAGES:
                 np.random.randint(2)  # the reference draws (and ignores) a flag here, dataset_mapper.py:93
                 picks = np.random.choice(len(self.mosaic_pool), self.mosaic_transform.NUM_IMAGES - 1)
                 mosaic_samples = [self.mosaic_pool[int(i)] for i in picks]
-            self.mosaic_pool.append(copy.deepcopy(dataset_dict))
+            self.mosaic_pool.append(_copy_dict(dataset_dict))
 
         first = self._load_image_with_anns(dataset_dict)
         if self.is_train and self.mosaic_transform.ENABLE and mosaic_samples is not None:
@@ -99,13 +106,13 @@ class YOLOV3DatasetMapper:
             mosaic_border = (-mh // 2, -mw // 2)
             yc, xc = [int(np.random.uniform(-x, s * 2 + x)) for x, s in zip(mosaic_border, [mh, mw])]
             for m_idx in range(self.mosaic_transform.NUM_IMAGES):
-                item = first if m_idx == 0 else self._load_image_with_anns(copy.deepcopy(mosaic_samples[m_idx - 1]))
+                item = first if m_idx == 0 else self._load_image_with_anns(_copy_dict(mosaic_samples[m_idx - 1]))
                 out_annos.extend(self._blend_mosaic(m_idx, item, out, xc, yc, mw, mh, jobs, keep))
             annos, image_hw = out_annos, (mh * 2, mw * 2)
         else:
             h, w = first.shape[:2]
             out = torch.empty((3, h, w), dtype=torch.uint8, device=self.device)
-            jobs.append(fused_job(first.tail, first.resized, out, planar=True))
+            jobs.append(fused_job(first.tail, first.resized, out, planar=True, reversed_source=self.image_format == "RGB"))
             keep.append(first.resized)
             annos, image_hw = first.annos, (h, w)
 
@@ -122,17 +129,24 @@ class YOLOV3DatasetMapper:
         dataset_dict.pop("annotations", None)
         return dataset_dict
 
+    def _launch(self, jobs: list) -> None:
+        if self._resizes:
+            ops.aug_resample_batch([r[0] for r in self._resizes], [r[1] for r in self._resizes], [r[2] for r in self._resizes])
+            self._resizes = []
+        ops.aug_apply(jobs)
+
     def __call__(self, dataset_dict: dict) -> dict:
         jobs, keep = [], []
         out = self._plan(dataset_dict, jobs, keep)
-        ops.aug_apply(jobs)
+        self._launch(jobs)
         return out
 
     def map_batch(self, dataset_dicts: List[dict]) -> List[dict]:
-        """``[self(d) for d in dataset_dicts]`` with one fused-pass launch per 16 source images."""
+        """``[self(d) for d in dataset_dicts]`` with the resizes and the fused passes of the whole batch launched
+        together (16 source images per launch)."""
         jobs, keep = [], []
         outs = [self._plan(d, jobs, keep) for d in dataset_dicts]
-        ops.aug_apply(jobs)
+        self._launch(jobs)
         return outs
 
     # ------------------------------------------------------------------------------------------
@@ -154,7 +168,8 @@ class YOLOV3DatasetMapper:
         # numpy slice assignment semantics of `out[y1a:y2a, x1a:x2a] = image[y1b:y2b, x1b:x2b]` for in-range rectangles
         cw, ch = min(x2a - x1a, x2b - x1b), min(y2a - y1a, y2b - y1b)
         if cw > 0 and ch > 0:
-            jobs.append(fused_job(item.tail, item.resized, out, dst_xy=(x1a, y1a), crop=(x1b, y1b, cw, ch), planar=True))
+            jobs.append(fused_job(item.tail, item.resized, out, dst_xy=(x1a, y1a), crop=(x1b, y1b, cw, ch), planar=True,
+                                  reversed_source=self.image_format == "RGB"))
             keep.append(item.resized)
         padw, padh = x1a - x1b, y1a - y1b
         annos = item.annos or []
@@ -170,19 +185,25 @@ class YOLOV3DatasetMapper:
 
     def _load_image_with_anns(self, dataset_dict: dict) -> _Planned:
         """dataset_mapper.py:171-202: read, draw the transforms, resize on the device, transform the annotations."""
+        # The image travels as decoded (BGR); for INPUT.FORMAT "RGB" the reference reverses the channels on the host
+        # (detection_utils.py:13-14) -- here the fused pass does it while writing, every step before being blind to
+        # the channel order except the colour jitter, which is told.
         if "image" in dataset_dict and not isinstance(dataset_dict["image"], str):
             image = np.asarray(dataset_dict["image"])
-            if self.image_format == "RGB":
-                image = image[:, :, ::-1]
         else:
-            image = read_image(dataset_dict["file_name"], format=self.image_format)
+            image = read_bgr(dataset_dict["file_name"])
         if "height" in dataset_dict or "width" in dataset_dict:  # utils.check_image_size
             assert (dataset_dict.get("height", image.shape[0]), dataset_dict.get("width", image.shape[1])) == image.shape[:2], \
                 "mismatched image shape"
         transforms: TransformList = self.augmentations.plan(image)
         dev = as_device_image(image, self.device)
         tail = list(transforms.transforms)
-        if tail and isinstance(tail[0], (ResizeTransform, LetterBoxTransform)):
+        if tail and isinstance(tail[0], ResizeTransform):  # deferred: all resizes of a batch go out together
+            t = tail.pop(0)
+            out = torch.empty((t.new_h, t.new_w, 3), dtype=torch.uint8, device=self.device)
+            self._resizes.append((dev, (t.new_h, t.new_w), out))
+            dev = out
+        elif tail and isinstance(tail[0], LetterBoxTransform):
             dev = tail.pop(0).apply_image(dev)
         image_shape = tuple(dev.shape[:2])
         annos = None

@@ -8,20 +8,24 @@ import numpy as np
 from .augmentation_impl import LetterBox, RandomAffine, RandomColorJitter, RandomFlip, ResizeShortestEdge
 
 
-def read_image(file_name, format=None) -> np.ndarray:
-    """detection_utils.py:8-15: HWC uint8 in BGR order (what cv2.imread returns), RGB if ``format == "RGB"``.
-    Files are decoded with Pillow (OpenCV is not a dependency here); ``.npy`` files hold the BGR array itself."""
+def read_bgr(file_name) -> np.ndarray:
+    """The decoded image as cv2.imread returns it: HWC uint8, BGR.  Files are decoded with Pillow (OpenCV is not a
+    dependency here); ``.npy`` files hold the BGR array itself."""
     assert os.path.exists(file_name), FileNotFoundError(f"{file_name}")
+    if str(file_name).endswith(".npy"):
+        return np.ascontiguousarray(np.load(file_name))
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(file_name).convert("RGB"))[:, :, ::-1])
+
+
+def read_image(file_name, format=None) -> np.ndarray:
+    """detection_utils.py:8-15: BGR, or RGB if ``format == "RGB"``."""
     if format:
         assert format in ["BGR", "RGB"], ValueError("Only support `BGR` or `RGB` format")
-    if str(file_name).endswith(".npy"):
-        image = np.load(file_name)
-    else:
-        from PIL import Image
-        image = np.asarray(Image.open(file_name).convert("RGB"))[:, :, ::-1]
+    image = read_bgr(file_name)
     if format and format == "RGB":
-        image = image[:, :, ::-1]
-    return np.ascontiguousarray(image)
+        image = np.ascontiguousarray(image[:, :, ::-1])
+    return image
 
 
 def build_augmentation(cfg, is_train: bool = True):

@@ -269,9 +269,11 @@ class LetterBoxTransform(Transform):
 
 
 def fused_job(transforms: Sequence[Transform], src: torch.Tensor, dst: torch.Tensor, dst_xy=(0, 0), crop=None,
-              planar: bool = False):
+              planar: bool = False, reversed_source: bool = False):
     """One ``yolo_aug_job`` for [AffineTransform] [ColorJitterTransform] [H/VFlipTransform] (each optional, in the
-    order the reference's lists produce them, detection_utils.py:57-86,106-135) applied to ``src``."""
+    order the reference's lists produce them, detection_utils.py:57-86,106-135) applied to ``src``.
+    ``reversed_source``: ``src`` holds the channels in the opposite order to the one the transforms were built for
+    (a BGR upload for an RGB pipeline); the pass converts while writing."""
     kw: dict = {}
     stage = 0
     for t in transforms:
@@ -281,7 +283,7 @@ def fused_job(transforms: Sequence[Transform], src: torch.Tensor, dst: torch.Ten
             kw.update(t.warp_arguments())
             stage = 1
         elif isinstance(t, ColorJitterTransform) and stage < 2:
-            kw.update(jitter=(t.hue, t.saturation, t.exposure), rgb=t.rgb)
+            kw.update(jitter=(t.hue, t.saturation, t.exposure), rgb=t.rgb != reversed_source)
             stage = 2
         elif isinstance(t, HFlipTransform) and stage < 3:
             kw.update(flip_horizontal=True)
@@ -291,4 +293,5 @@ def fused_job(transforms: Sequence[Transform], src: torch.Tensor, dst: torch.Ten
             stage = 3
         else:
             raise ValueError(f"fused_job: {type(t).__name__} cannot be folded at this position")
-    return ops.aug_job(src, dst, dst_xy=dst_xy, crop=crop, border=BORDER_VALUE, planar=planar, **kw)
+    return ops.aug_job(src, dst, dst_xy=dst_xy, crop=crop, border=BORDER_VALUE, planar=planar,
+                       reverse_channels=reversed_source, **kw)

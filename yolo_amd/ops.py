@@ -650,14 +650,49 @@ def aug_resample(src: torch.Tensor, out_hw: Tuple[int, int], out: Optional[torch
     return out
 
 
+def aug_resample_batch(srcs: Sequence[torch.Tensor], out_hws: Sequence[Tuple[int, int]],
+                       outs: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+    """``aug_resample`` for many images with two launches per 16 images."""
+    n = len(srcs)
+    if n == 0:
+        return []
+    dev = srcs[0].device
+    if outs is None:
+        outs = [torch.empty((h, w, 3), dtype=torch.uint8, device=dev) for h, w in out_hws]
+    need = [int(s.shape[0]) * w * 3 if (s.shape[0] != h and s.shape[1] != w) else 0 for s, (h, w) in zip(srcs, out_hws)]
+    ws = torch.empty(max(sum(need), 1), dtype=torch.uint8, device=dev)
+    arr = (_lib.AugResampleJob * n)()
+    off = 0
+    for j, s, o, (nh, nw), nbytes in zip(arr, srcs, outs, out_hws, need):
+        _check_image(s, "aug_resample_batch")
+        _check_image(o, "aug_resample_batch")
+        assert tuple(o.shape[:2]) == (nh, nw), (o.shape, nh, nw)
+        H, W = int(s.shape[0]), int(s.shape[1])
+        j.src, j.dst = s.data_ptr(), o.data_ptr()
+        j.src_stride, j.dst_stride = s.stride(0), o.stride(0)
+        j.src_height, j.src_width, j.dst_height, j.dst_width = H, W, nh, nw
+        if nw != W:
+            xb, xc, j.x_ksize = resample_tables(W, nw, dev)
+            j.x_bounds, j.x_coef = xb.data_ptr(), xc.data_ptr()
+        if nh != H:
+            yb, yc, j.y_ksize = resample_tables(H, nh, dev)
+            j.y_bounds, j.y_coef = yb.data_ptr(), yc.data_ptr()
+        if nbytes:
+            j.workspace, j.workspace_bytes = ws.data_ptr() + off, nbytes
+            off += nbytes
+    check(lib().yolo_aug_resample_batch(ctypes.cast(arr, ctypes.c_void_p), n, _stream()), "yolo_aug_resample_batch")
+    return list(outs)
+
+
 def aug_job(src: torch.Tensor, dst: torch.Tensor, *, dst_xy: Tuple[int, int] = (0, 0),
             crop: Optional[Tuple[int, int, int, int]] = None, inverse_map=None, perspective: bool = False,
             jitter: Optional[Tuple[float, float, float]] = None, rgb: bool = False, flip_horizontal: bool = False,
-            flip_vertical: bool = False, border: int = 114, planar: bool = False) -> "_lib.AugJob":
+            flip_vertical: bool = False, border: int = 114, planar: bool = False,
+            reverse_channels: bool = False) -> "_lib.AugJob":
     """One image's fused warp -> colour jitter -> flip -> paste.  ``inverse_map``: 6 (affine) or 9 (perspective)
     doubles taking output pixels to source pixels; ``crop`` = (x, y, w, h) of the augmented image (default: all);
     ``dst_xy``: where the crop lands in ``dst``; ``planar``: ``dst`` is a [3, H, W] tensor (the model's input layout)
-    instead of [H, W, 3].  The job holds raw pointers: keep ``src`` / ``dst`` alive."""
+    instead of [H, W, 3]; ``reverse_channels``: write channel 2, 1, 0 (``rgb`` describes ``src``).  The job holds raw pointers: keep ``src`` / ``dst`` alive."""
     _check_image(src, "aug_job")
     j = _lib.AugJob()
     j.src, j.dst = src.data_ptr(), dst.data_ptr()
@@ -686,6 +721,7 @@ def aug_job(src: torch.Tensor, dst: torch.Tensor, *, dst_xy: Tuple[int, int] = (
         j.hue_gain, j.saturation_gain, j.exposure_gain = (float(v) for v in jitter)
     j.rgb_order = int(rgb)
     j.flip_horizontal, j.flip_vertical, j.border = int(flip_horizontal), int(flip_vertical), border
+    j.reverse_channels = int(reverse_channels)
     return j
 
 
