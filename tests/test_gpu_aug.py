@@ -301,3 +301,23 @@ def test_mapper_output_feeds_the_training_step(cuda):
     total = sum(losses.values())
     assert torch.isfinite(total)
     total.backward()
+
+
+def test_hbm_resident_source_cache_changes_nothing(cuda):
+    """With ``cache_bytes`` the decoded sources stay in HBM after their first use; outputs are the same bytes."""
+    import os
+    from yolo_amd.config import get_cfg
+    from yolo_amd.data import YOLOV3DatasetMapper
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "yolov3-aug.yaml"))
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (160,), "INPUT.MAX_SIZE_TRAIN", 160, "INPUT.MOSAIC.MOSAIC_WIDTH", 160,
+                         "INPUT.MOSAIC.MOSAIC_HEIGHT", 160])
+    data = _dataset(8, 9)
+    runs = []
+    for cache in (0, 1 << 30):
+        np.random.seed(2)
+        random.seed(2)
+        mapper = YOLOV3DatasetMapper(cfg, True, cache_bytes=cache)
+        runs.append([o["image"].cpu() for o in mapper.map_batch(data) + mapper.map_batch(data)])
+        assert len(mapper._cache) == (8 if cache else 0)
+    assert all(torch.equal(a, b) for a, b in zip(*runs))

@@ -131,6 +131,17 @@ def main():
     t_m = time.perf_counter() - t0
     rows.append(dict(stage="YOLOV3DatasetMapper.map_batch incl. host planning and upload", ms=round(t_m * 1e3, 1),
                      mosaic_outputs_per_s=round(n_out / t_m)))
+    cached = YOLOV3DatasetMapper(cfg, True, cache_bytes=1 << 30)
+    for i, d in enumerate(data):
+        d["image_id"] = i % 8
+    cached.map_batch(data[:8])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cached.map_batch(data[8:])
+    torch.cuda.synchronize()
+    t_c = time.perf_counter() - t0
+    rows.append(dict(stage="YOLOV3DatasetMapper.map_batch, sources resident in HBM (cache_bytes)", ms=round(t_c * 1e3, 1),
+                     mosaic_outputs_per_s=round(n_out / t_c)))
     # CPU: one core
     from PIL import Image
     from oracle import aug_ref as A

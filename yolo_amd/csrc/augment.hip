@@ -89,7 +89,8 @@ struct PassJob {
     const int* bounds;  // [n_out][2]: first source index, count
     const int* coef;    // [n_out][ksize]
     int ksize;
-    int mode;  // 0 horizontal, 1 vertical, 2 copy
+    int mode;    // 0 horizontal, 1 vertical, 2 copy
+    int in_len;  // source columns (horizontal) or rows (vertical)
 };
 static constexpr int AUG_MAX_PASS_JOBS = 16;
 struct PassJobs {
@@ -101,64 +102,109 @@ __device__ __forceinline__ uint8_t clip8(int a) {
     return (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
 }
 
+// KTAPS > 0: every job of the launch has exactly KTAPS coefficients per output (3 when enlarging, 5 / 7 when
+// shrinking by up to 2x / 3x): all loads of a thread are issued together.  Coefficients beyond an output's own
+// count are zero in the tables, so reading KTAPS in-range source elements is the same sum.  KTAPS == 0: any size.
+template <int KTAPS>
 __global__ void __launch_bounds__(AUG_THREADS) aug_resample_kernel(const PassJobs jobs) {
     const PassJob& p = jobs.j[blockIdx.y];
-    const long long idx = (long long)blockIdx.x * AUG_THREADS + threadIdx.x;
+    const unsigned idx = blockIdx.x * AUG_THREADS + threadIdx.x;
     if (p.mode == 0) {
         // one output pixel per thread
-        if (idx >= (long long)p.out_h * p.out_w) return;
-        const int y = (int)(idx / p.out_w), x = (int)(idx - (long long)y * p.out_w);
+        if (idx >= (unsigned)p.out_h * (unsigned)p.out_w) return;
+        const unsigned y = idx / (unsigned)p.out_w, x = idx - y * (unsigned)p.out_w;
         const int first = p.bounds[2 * x], n = p.bounds[2 * x + 1];
         const int* k = p.coef + (long long)x * p.ksize;
         int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
         const uint8_t* s = p.src + y * p.s_stride + 3 * first;
-        for (int i = 0; i < n; ++i) {
-            const int w = k[i];
-            a0 += s[0] * w;
-            a1 += s[1] * w;
-            a2 += s[2] * w;
-            s += 3;
+        bool done = false;
+        if constexpr (KTAPS > 0) {
+            if (first + KTAPS <= p.in_len) {
+                uint8_t px[3 * KTAPS];
+                int w[KTAPS];
+                __builtin_memcpy(px, s, 3 * KTAPS);
+#pragma unroll
+                for (int i = 0; i < KTAPS; ++i) w[i] = k[i];
+#pragma unroll
+                for (int i = 0; i < KTAPS; ++i) {
+                    a0 += px[3 * i] * w[i];
+                    a1 += px[3 * i + 1] * w[i];
+                    a2 += px[3 * i + 2] * w[i];
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            for (int i = 0; i < n; ++i) {
+                const int w = k[i];
+                a0 += s[0] * w;
+                a1 += s[1] * w;
+                a2 += s[2] * w;
+                s += 3;
+            }
         }
         uint8_t* d = p.dst + y * p.d_stride + 3 * x;
         d[0] = clip8(a0);
         d[1] = clip8(a1);
         d[2] = clip8(a2);
     } else {
-        // four consecutive bytes of an output row per thread: the taps are whole rows, read 4 bytes at a time
-        const int row_bytes = 3 * p.out_w, quads = (row_bytes + 3) >> 2;
-        if (idx >= (long long)p.out_h * quads) return;
-        const int y = (int)(idx / quads), b = (int)(idx - (long long)y * quads) * 4;
-        const int nb = row_bytes - b < 4 ? row_bytes - b : 4;
-        int first = y, n = 1;
+        // eight consecutive bytes of an output row per thread: the taps are whole rows, read 8 bytes at a time
+        const unsigned row_bytes = 3u * (unsigned)p.out_w, octs = (row_bytes + 7u) >> 3;
+        if (idx >= (unsigned)p.out_h * octs) return;
+        const unsigned y = idx / octs, b = (idx - y * octs) * 8u;
+        const int nb = row_bytes - b < 8u ? (int)(row_bytes - b) : 8;
+        int first = (int)y, n = 1;
         const int* k = nullptr;
         if (p.mode == 1) {
             first = p.bounds[2 * y];
             n = p.bounds[2 * y + 1];
             k = p.coef + (long long)y * p.ksize;
         }
-        int a[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
-        const uint8_t* s = p.src + first * p.s_stride + b;
-        for (int i = 0; i < n; ++i) {
-            const int w = k ? k[i] : (1 << 22);
-            uint32_t v = 0;
-            if (nb == 4) {
-                __builtin_memcpy(&v, s, 4);
-            } else {
-                for (int e = 0; e < nb; ++e) v |= (uint32_t)s[e] << (8 * e);
-            }
+        int a[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] += (int)((v >> (8 * e)) & 255u) * w;
-            s += p.s_stride;
+        for (int e = 0; e < 8; ++e) a[e] = 1 << 21;
+        const uint8_t* s = p.src + first * p.s_stride + b;
+        bool done = false;
+        if constexpr (KTAPS > 0) {
+            if (p.mode == 1 && nb == 8 && first + KTAPS <= p.in_len) {
+                uint64_t v[KTAPS];
+                int w[KTAPS];
+#pragma unroll
+                for (int i = 0; i < KTAPS; ++i) {
+                    __builtin_memcpy(&v[i], s + i * p.s_stride, 8);
+                    w[i] = k[i];
+                }
+#pragma unroll
+                for (int i = 0; i < KTAPS; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += (int)((v[i] >> (8 * e)) & 255u) * w[i];
+                done = true;
+            }
+        }
+        if (!done) {
+            for (int i = 0; i < n; ++i) {
+                const int w = k ? k[i] : (1 << 22);
+                uint64_t v = 0;
+                if (nb == 8) {
+                    __builtin_memcpy(&v, s, 8);
+                } else {
+                    for (int e = 0; e < nb; ++e) v |= (uint64_t)s[e] << (8 * e);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += (int)((v >> (8 * e)) & 255u) * w;
+                s += p.s_stride;
+            }
         }
         uint8_t* d = p.dst + y * p.d_stride + b;
         if (p.mode == 2) {  // copy: the accumulators hold 2^21 + v * 2^22
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] -= 1 << 21;
+            for (int e = 0; e < 8; ++e) a[e] -= 1 << 21;
         }
-        const uint32_t o = (uint32_t)clip8(a[0]) | ((uint32_t)clip8(a[1]) << 8) | ((uint32_t)clip8(a[2]) << 16) |
-                           ((uint32_t)clip8(a[3]) << 24);
-        if (nb == 4) {
-            __builtin_memcpy(d, &o, 4);
+        uint64_t o = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o |= (uint64_t)clip8(a[e]) << (8 * e);
+        if (nb == 8) {
+            __builtin_memcpy(d, &o, 8);
         } else {
             for (int e = 0; e < nb; ++e) d[e] = (uint8_t)(o >> (8 * e));
         }
@@ -388,14 +434,24 @@ static int launch_passes(const PassJob* jobs, int n, hipStream_t st) {
         const int m = n - first < AUG_MAX_PASS_JOBS ? n - first : AUG_MAX_PASS_JOBS;
         PassJobs batch{};
         long long most = 0;
+        int taps = -1;  // the common coefficient count of the launch's jobs, 0 if they differ
         for (int i = 0; i < m; ++i) {
             batch.j[i] = jobs[first + i];
             const PassJob& p = batch.j[i];
-            const long long work = p.mode == 0 ? (long long)p.out_h * p.out_w : (long long)p.out_h * ((3 * p.out_w + 3) >> 2);
+            const long long work = p.mode == 0 ? (long long)p.out_h * p.out_w : (long long)p.out_h * ((3 * p.out_w + 7) >> 3);
             most = work > most ? work : most;
+            const int k = p.mode == 2 ? 0 : p.ksize;
+            taps = taps < 0 ? k : (taps == k ? taps : 0);
         }
-        hipLaunchKernelGGL(aug_resample_kernel, dim3((unsigned)((most + AUG_THREADS - 1) / AUG_THREADS), m),
-                           dim3(AUG_THREADS), 0, st, batch);
+        const dim3 grid((unsigned)((most + AUG_THREADS - 1) / AUG_THREADS), m), block(AUG_THREADS);
+        if (taps == 3)
+            hipLaunchKernelGGL(aug_resample_kernel<3>, grid, block, 0, st, batch);
+        else if (taps == 5)
+            hipLaunchKernelGGL(aug_resample_kernel<5>, grid, block, 0, st, batch);
+        else if (taps == 7)
+            hipLaunchKernelGGL(aug_resample_kernel<7>, grid, block, 0, st, batch);
+        else
+            hipLaunchKernelGGL(aug_resample_kernel<0>, grid, block, 0, st, batch);
         YOLO_CHECK_HIP(hipGetLastError());
     }
     return YOLO_OK;
@@ -416,6 +472,8 @@ extern "C" int yolo_aug_resample_batch(const yolo_aug_resample_job* jobs, int n_
             rc = fail(YOLO_E_ARG, "aug_resample: job %d: sizes must be positive", i);
         else if (!(j.src_stride >= 3ll * j.src_width && j.dst_stride >= 3ll * j.dst_width))
             rc = fail(YOLO_E_ARG, "aug_resample: job %d: row stride below 3 * width", i);
+        else if ((long long)(j.src_height > j.dst_height ? j.src_height : j.dst_height) * j.dst_width >= (1ll << 30))
+            rc = fail(YOLO_E_ARG, "aug_resample: job %d: image too large", i);
         else if (horiz && !(j.x_bounds && j.x_coef && j.x_ksize > 0))
             rc = fail(YOLO_E_ARG, "aug_resample: job %d: horizontal tables missing", i);
         else if (vert && !(j.y_bounds && j.y_coef && j.y_ksize > 0))
@@ -432,6 +490,7 @@ extern "C" int yolo_aug_resample_batch(const yolo_aug_resample_job* jobs, int n_
             p.s_stride = j.src_stride;
             p.out_h = j.src_height;
             p.out_w = j.dst_width;
+            p.in_len = j.src_width;
             p.mode = horiz ? 0 : 2;
             p.bounds = j.x_bounds;
             p.coef = j.x_coef;
@@ -455,6 +514,7 @@ extern "C" int yolo_aug_resample_batch(const yolo_aug_resample_job* jobs, int n_
             p.d_stride = j.dst_stride;
             p.out_h = j.dst_height;
             p.out_w = j.dst_width;
+            p.in_len = j.src_height;
             p.mode = 1;
             p.bounds = j.y_bounds;
             p.coef = j.y_coef;

@@ -62,7 +62,7 @@ class YOLOV3DatasetMapper:
 
     def _init(self, is_train: bool, *, augmentations: List[Union[Augmentation, Transform]], image_format: str,
               mosaic_transform, use_instance_mask: bool = False, instance_mask_format: str = "polygon",
-              recompute_boxes: bool = False, device="cuda"):
+              recompute_boxes: bool = False, device="cuda", cache_bytes: int = 0):
         if use_instance_mask or recompute_boxes:
             raise NotImplementedError("instance masks are outside this mapper")
         self.is_train = is_train
@@ -72,6 +72,9 @@ class YOLOV3DatasetMapper:
         mode = "training" if is_train else "inference"
         logging.getLogger(__name__).info(f"[DatasetMapper] Augmentations used in {mode}: {augmentations}")
         self._resizes: list = []
+        # decoded source images kept in HBM, keyed by file name / image id, up to cache_bytes (0 = off): a uint8
+        # detection data set is ~1 MB per image, so one GPU's 288 GB hold it whole and later epochs skip PCIe
+        self.cache_bytes, self._cached_bytes, self._cache = int(cache_bytes), 0, {}
         self.mosaic_transform = mosaic_transform
         if self.mosaic_transform.ENABLE:
             self.mosaic_pool = deque(maxlen=self.mosaic_transform.POOL_CAPACITY)
@@ -188,15 +191,23 @@ class YOLOV3DatasetMapper:
         # The image travels as decoded (BGR); for INPUT.FORMAT "RGB" the reference reverses the channels on the host
         # (detection_utils.py:13-14) -- here the fused pass does it while writing, every step before being blind to
         # the channel order except the colour jitter, which is told.
-        if "image" in dataset_dict and not isinstance(dataset_dict["image"], str):
+        key = dataset_dict.get("file_name", dataset_dict.get("image_id")) if self.cache_bytes else None
+        dev = self._cache.get(key) if key is not None else None
+        if dev is not None:
+            image = dev  # only its shape is read below
+        elif "image" in dataset_dict and not isinstance(dataset_dict["image"], str):
             image = np.asarray(dataset_dict["image"])
         else:
             image = read_bgr(dataset_dict["file_name"])
         if "height" in dataset_dict or "width" in dataset_dict:  # utils.check_image_size
-            assert (dataset_dict.get("height", image.shape[0]), dataset_dict.get("width", image.shape[1])) == image.shape[:2], \
-                "mismatched image shape"
+            assert (dataset_dict.get("height", image.shape[0]), dataset_dict.get("width", image.shape[1])) == \
+                tuple(image.shape[:2]), "mismatched image shape"
         transforms: TransformList = self.augmentations.plan(image)
-        dev = as_device_image(image, self.device)
+        if dev is None:
+            dev = as_device_image(image, self.device)
+            if key is not None and self._cached_bytes + dev.numel() <= self.cache_bytes:
+                self._cache[key] = dev
+                self._cached_bytes += dev.numel()
         tail = list(transforms.transforms)
         if tail and isinstance(tail[0], ResizeTransform):  # deferred: all resizes of a batch go out together
             t = tail.pop(0)
