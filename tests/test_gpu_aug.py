@@ -321,3 +321,23 @@ def test_hbm_resident_source_cache_changes_nothing(cuda):
         runs.append([o["image"].cpu() for o in mapper.map_batch(data) + mapper.map_batch(data)])
         assert len(mapper._cache) == (8 if cache else 0)
     assert all(torch.equal(a, b) for a, b in zip(*runs))
+
+
+def test_trainer_runs_on_augmented_batches(cuda):
+    """Trainer over ``augmented_batches`` (the mapper as the training loader): losses stay finite, weights move."""
+    import workload
+    from yolo_amd.trainer import Trainer, augmented_batches
+    model, cfg = workload.build_model(config="yolov3-aug.yaml", dtype="bf16",
+                                      opts=["INPUT.MIN_SIZE_TRAIN", (160,), "INPUT.MAX_SIZE_TRAIN", 160,
+                                            "INPUT.MOSAIC.MOSAIC_WIDTH", 160, "INPUT.MOSAIC.MOSAIC_HEIGHT", 160,
+                                            "SOLVER.IMS_PER_BATCH", 4, "SOLVER.BASE_LR", 1e-4])
+    data = augmented_batches(cfg, 4, seed=3, n_images=12, device=model.device)
+    sizes = {tuple(d["image"].shape) for _ in range(3) for d in next(data)}
+    assert (3, 320, 320) in sizes  # mosaics appear once the pool holds more than four images
+    lines = []
+    trainer = Trainer(cfg, model, data, log=lines.append)
+    w0 = model.backbone.bottom_up.res5[0].conv1.weight.detach().float().clone()
+    for _ in range(3):
+        losses = trainer.run_step()
+        assert all(bool(torch.isfinite(v)) for v in losses.values())
+    assert not torch.equal(w0, model.backbone.bottom_up.res5[0].conv1.weight.detach().float())

@@ -38,6 +38,8 @@ def default_argument_parser():
     p.add_argument("--synthetic", action="store_true", default=True, help="train on synthetic COCO-shaped targets")
     p.add_argument("--train-size", type=int, default=416, help="training image side (multiple of 32)")
     p.add_argument("--multi-scale", action="store_true", help="draw the side per step from 320..608 step 32")
+    p.add_argument("--augment", action="store_true",
+                   help="feed the model through YOLOV3DatasetMapper (GPU augmentation of a synthetic in-memory dataset)")
     p.add_argument("--max-iter", type=int, default=None, help="override SOLVER.MAX_ITER")
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     return p
@@ -61,7 +63,11 @@ def main(args):
         from yolo_amd.trainer import Trainer, synthetic_batches
         per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // world, 1)
         sizes = list(range(320, 609, 32)) if args.multi_scale else None
-        data = synthetic_batches(cfg, per_gpu, args.train_size, seed=7 + rank, device=model.device, sizes=sizes)
+        if args.augment:
+            from yolo_amd.trainer import augmented_batches
+            data = augmented_batches(cfg, per_gpu, seed=7 + rank, device=model.device)
+        else:
+            data = synthetic_batches(cfg, per_gpu, args.train_size, seed=7 + rank, device=model.device, sizes=sizes)
         trainer = Trainer(cfg, model, data, log=lambda m: print(f"[rank {rank}] {m}") if rank == 0 else None)
         trainer.resume_or_load(resume=args.resume)
         trainer.train(max_iter=args.max_iter)

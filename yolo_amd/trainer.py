@@ -42,6 +42,54 @@ def synthetic_batches(cfg, per_gpu: int, size: int, *, seed: int = 7, max_boxes:
         yield batch
 
 
+def synthetic_dataset(cfg, n_images: int = 64, *, seed: int = 7, max_boxes: int = 20, min_side: int = 320,
+                      max_side: int = 640) -> List[Dict]:
+    """Dataset dicts in detectron2's format with in-memory images (HWC uint8, BGR as decoded): random sizes, K ~
+    U{1..max_boxes} XYXY boxes inside the frame, classes uniform -- a stand-in for a registered dataset."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    C = cfg.MODEL.YOLOV3.NUM_CLASSES
+    out = []
+    for i in range(n_images):
+        h, w = int(rng.integers(min_side, max_side + 1)), int(rng.integers(min_side, max_side + 1))
+        k = int(rng.integers(1, max_boxes + 1))
+        wh = 8 + rng.random((k, 2)) * (np.array([w, h]) * 0.6 - 8)
+        xy = rng.random((k, 2)) * (np.array([w, h]) - wh)
+        annos = [dict(bbox=[float(xy[j, 0]), float(xy[j, 1]), float(xy[j, 0] + wh[j, 0]), float(xy[j, 1] + wh[j, 1])],
+                      bbox_mode=0, category_id=int(rng.integers(0, C))) for j in range(k)]
+        out.append(dict(image=rng.integers(0, 256, (h, w, 3), dtype=np.uint8), height=h, width=w, image_id=i,
+                        annotations=annos))
+    return out
+
+
+def augmented_batches(cfg, per_gpu: int, *, seed: int = 7, n_images: int = 64, device="cuda",
+                      cache_bytes: int = 1 << 32) -> Iterator[List[Dict]]:
+    """Endless training batches through the reference's input pipeline (tools/train_net.py:109-111:
+    ``build_detection_train_loader(cfg, mapper=YOLOV3DatasetMapper(cfg, True))``) over a synthetic in-memory dataset:
+    the augmentation the config asks for (resize / letterbox, random affine, colour jitter, flip, mosaic) runs on
+    the GPU, sources stay resident in HBM after their first use."""
+    import random
+
+    import numpy as np
+
+    from .data import YOLOV3DatasetMapper
+    np.random.seed(seed)
+    random.seed(seed)
+    data = synthetic_dataset(cfg, n_images, seed=seed)
+    mapper = YOLOV3DatasetMapper(cfg, True, device=device, cache_bytes=cache_bytes)
+    order = np.random.default_rng(seed)
+    while True:
+        picks = order.integers(0, len(data), per_gpu)
+        batch = mapper.map_batch([data[int(i)] for i in picks])
+        for d in batch:
+            if "instances" in d:
+                d["instances"] = d["instances"].to(device)
+            else:
+                d["instances"] = Instances(tuple(d["image"].shape[-2:]), gt_boxes=Boxes(torch.zeros((0, 4), device=device)),
+                                           gt_classes=torch.zeros((0,), dtype=torch.int64, device=device))
+        yield batch
+
+
 class Trainer:
     def __init__(self, cfg, model, data: Iterable[List[Dict]], *, log: Callable[[str], None] = print):
         self.cfg, self.model, self.data, self.log = cfg, model, iter(data), log
