@@ -234,8 +234,8 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jo
     const yolo_aug_job& J = jobs.j[blockIdx.y];
     __shared__ uint8_t lut[3][256];
     __shared__ int sdiv[256], hdiv[256];
-    const long long npix = (long long)J.crop_w * J.crop_h;
-    const long long base = (long long)blockIdx.x * (AUG_THREADS * AUG_PIX_PER_THREAD);
+    const unsigned npix = (unsigned)J.crop_w * (unsigned)J.crop_h;
+    const unsigned base = blockIdx.x * (unsigned)(AUG_THREADS * AUG_PIX_PER_THREAD);
     if (base >= npix) return;  // whole block
     if (J.jitter) {
         const int t = threadIdx.x;
@@ -257,9 +257,9 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jo
     uint8_t* D = (uint8_t*)J.dst;
     const int W = J.src_width, H = J.src_height;
     for (int it = 0; it < AUG_PIX_PER_THREAD; ++it) {
-        const long long idx = base + (long long)it * AUG_THREADS + threadIdx.x;
+        const unsigned idx = base + (unsigned)it * AUG_THREADS + threadIdx.x;
         if (idx >= npix) break;
-        const int py = (int)(idx / J.crop_w), px = (int)(idx - (long long)py * J.crop_w);
+        const int py = (int)(idx / (unsigned)J.crop_w), px = (int)(idx - (unsigned)py * (unsigned)J.crop_w);
         int u = J.crop_x + px, v = J.crop_y + py;
         if (J.flip_horizontal) u = W - 1 - u;
         if (J.flip_vertical) v = H - 1 - v;
@@ -569,6 +569,7 @@ extern "C" int yolo_aug_apply(const yolo_aug_job* jobs, int n_jobs, void* stream
                                              : j.dst_stride >= 3ll * j.dst_width),
                      "aug_apply: job %d: paste at (%d,%d) of %dx%d outside the %dx%d canvas", i, j.dst_x, j.dst_y, j.crop_w,
                      j.crop_h, j.dst_width, j.dst_height);
+        YOLO_REQUIRE((long long)j.crop_w * j.crop_h < (1ll << 31), "aug_apply: job %d: crop too large", i);
         YOLO_REQUIRE(j.warp >= 0 && j.warp <= 2, "aug_apply: job %d: warp mode %d", i, j.warp);
         YOLO_REQUIRE(j.border >= 0 && j.border <= 255, "aug_apply: job %d: border value %d", i, j.border);
     }
