@@ -220,15 +220,31 @@ struct AugJobs {
     yolo_aug_job j[AUG_MAX_JOBS];
 };
 
+// cv2's saturate_cast<int>(double): round to nearest even, clamp to the int range
 __device__ __forceinline__ long long sat_int(double v) {
     v = rint(v);
     v = fmin(fmax(v, -2147483648.0), 2147483647.0);
-    return (long long)v;
+    return (long long)(int)v;
 }
 
-// 12-bit reciprocal tables of OpenCV's 8-bit RGB -> HSV: round((255 << 12) / i), round((180 << 12) / (6 i))
-__device__ __forceinline__ int sdiv12(int i) { return i ? (int)rint((double)(255 << 12) / (1.0 * i)) : 0; }
-__device__ __forceinline__ int hdiv12(int i) { return i ? (int)rint((double)(180 << 12) / (6.0 * i)) : 0; }
+// 12-bit reciprocal tables of OpenCV's 8-bit RGB -> HSV: round((255 << 12) / i) and round((180 << 12) / (6 i)),
+// rounded to nearest even -- exact integer arithmetic at compile time.
+struct DivTables {
+    int s[256], h[256];
+};
+constexpr int rounded_quotient(int n, int d) {
+    const int q = n / d, r = n % d;
+    return 2 * r > d ? q + 1 : (2 * r == d ? q + (q & 1) : q);
+}
+constexpr DivTables make_div_tables() {
+    DivTables t{};
+    for (int i = 1; i < 256; ++i) {
+        t.s[i] = rounded_quotient(255 << 12, i);
+        t.h[i] = rounded_quotient(30 << 12, i);
+    }
+    return t;
+}
+__constant__ DivTables c_div = make_div_tables();
 
 __global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jobs) {
     const yolo_aug_job& J = jobs.j[blockIdx.y];
@@ -249,17 +265,26 @@ __global__ void __launch_bounds__(AUG_THREADS) aug_apply_kernel(const AugJobs jo
             const double v = fmin(fmax((double)t * g[c], 0.0), 255.0);
             lut[c][t] = (uint8_t)(int)v;
         }
-        sdiv[t] = sdiv12(t);
-        hdiv[t] = hdiv12(t);
+        sdiv[t] = c_div.s[t];
+        hdiv[t] = c_div.h[t];
         __syncthreads();
     }
+    const float inv_w = 1.0f / (float)J.crop_w;
     const uint8_t* S = (const uint8_t*)J.src;
     uint8_t* D = (uint8_t*)J.dst;
     const int W = J.src_width, H = J.src_height;
     for (int it = 0; it < AUG_PIX_PER_THREAD; ++it) {
         const unsigned idx = base + (unsigned)it * AUG_THREADS + threadIdx.x;
         if (idx >= npix) break;
-        const int py = (int)(idx / (unsigned)J.crop_w), px = (int)(idx - (unsigned)py * (unsigned)J.crop_w);
+        // idx / crop_w through a float reciprocal, corrected by one either way (idx < 2^31, any crop_w)
+        int py = (int)((float)idx * inv_w), px = (int)idx - py * J.crop_w;
+        if (px < 0) {
+            --py;
+            px += J.crop_w;
+        } else if (px >= J.crop_w) {
+            ++py;
+            px -= J.crop_w;
+        }
         int u = J.crop_x + px, v = J.crop_y + py;
         if (J.flip_horizontal) u = W - 1 - u;
         if (J.flip_vertical) v = H - 1 - v;
