@@ -81,17 +81,16 @@ class RandomAffine(Augmentation):
 
     def get_transform(self, image) -> Transform:
         height, width = image.shape[:2]
-        angle = np.random.uniform(-self.degree, self.degree)
-        scale = np.random.uniform(1 - self.scale, 1 + self.scale)
-        translate_x = np.random.uniform(0.5 - self.translate, 0.5 + self.translate)
-        translate_y = np.random.uniform(0.5 - self.translate, 0.5 + self.translate)
-        shear_x = np.tan(np.random.uniform(-self.shear, self.shear) * np.pi / 180)
-        shear_y = np.tan(np.random.uniform(-self.shear, self.shear) * np.pi / 180)
-        perspective_x = random.uniform(-self.perspective, self.perspective)
-        perspective_y = random.uniform(-self.perspective, self.perspective)
-        return AffineTransform(height=height, width=width, angle=angle, scale=scale,
-                               translate=(translate_x, translate_y), shear=(shear_x, shear_y),
-                               perspective=(perspective_x, perspective_y))
+        # six numpy draws in the reference's order (angle, scale, translate x / y, shear x / y), then two from
+        # ``random`` for the projective terms
+        spans = [(-self.degree, self.degree), (1 - self.scale, 1 + self.scale),
+                 (0.5 - self.translate, 0.5 + self.translate), (0.5 - self.translate, 0.5 + self.translate),
+                 (-self.shear, self.shear), (-self.shear, self.shear)]
+        angle, scale, tx, ty, shx, shy = [np.random.uniform(lo, hi) for lo, hi in spans]
+        shear = tuple(np.tan(v * np.pi / 180) for v in (shx, shy))
+        persp = tuple(random.uniform(-self.perspective, self.perspective) for _ in range(2))
+        return AffineTransform(height=height, width=width, angle=angle, scale=scale, translate=(tx, ty), shear=shear,
+                               perspective=persp)
 
 
 class RandomColorJitter(Augmentation):

@@ -156,18 +156,24 @@ class YOLOV3DatasetMapper:
     def _blend_mosaic(self, idx, item: _Planned, out: torch.Tensor, xc, yc, mosaic_width, mosaic_height, jobs, keep):
         """dataset_mapper.py:136-169: where image ``idx`` lands on the canvas and which part of it is visible."""
         h, w = item.shape[:2]
-        if idx == 0:  # top left
-            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
-            x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
-        elif idx == 1:  # top right
-            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, mosaic_width * 2), yc
-            x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
-        elif idx == 2:  # bottom left
-            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(mosaic_height * 2, yc + h)
-            x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
-        else:  # bottom right
-            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, mosaic_width * 2), min(mosaic_height * 2, yc + h)
-            x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
+        canvas_w, canvas_h = 2 * mosaic_width, 2 * mosaic_height
+        right, bottom = bool(idx & 1), bool(idx & 2)   # 0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right
+        # The image touches the centre (xc, yc) with the corner facing it; the canvas cuts off what sticks out, and
+        # the part kept is the one next to the centre.
+        if right:
+            x1a, x2a = xc, min(xc + w, canvas_w)
+            x1b = 0
+        else:
+            x1a, x2a = max(xc - w, 0), xc
+            x1b = w - (x2a - x1a)
+        if bottom:
+            y1a, y2a = yc, min(yc + h, canvas_h)
+            y1b = 0
+        else:
+            y1a, y2a = max(yc - h, 0), yc
+            y1b = h - (y2a - y1a)
+        x2b = min(w, x2a - x1a) if right else w
+        y2b = min(y2a - y1a, h) if bottom else h
         # numpy slice assignment semantics of `out[y1a:y2a, x1a:x2a] = image[y1b:y2b, x1b:x2b]` for in-range rectangles
         cw, ch = min(x2a - x1a, x2b - x1b), min(y2a - y1a, y2b - y1b)
         if cw > 0 and ch > 0:

@@ -172,6 +172,31 @@ def invert_affine_2x3(M: np.ndarray) -> np.ndarray:
     return m
 
 
+def _matrix(**entries) -> np.ndarray:
+    """3x3 identity with the given entries replaced (``m02=...`` sets row 0, column 2)."""
+    m = np.eye(3)
+    for name, value in entries.items():
+        m[int(name[1]), int(name[2])] = value
+    return m
+
+
+def _compose_affine(height, width, angle, scale, translate, shear, perspective) -> np.ndarray:
+    """transforms.py:24-39: move the image centre to the origin, apply the projective terms, rotate and scale about
+    the origin, shear, then move by ``translate`` (fractions of the image size)."""
+    rot = rotation_matrix_2d(angle, scale)
+    steps = [
+        _matrix(m02=translate[0] * width, m12=translate[1] * height),
+        _matrix(m01=shear[0], m10=shear[1]),
+        _matrix(m00=rot[0, 0], m01=rot[0, 1], m10=rot[1, 0], m11=rot[1, 1]),
+        _matrix(m20=perspective[0], m21=perspective[1]),
+        _matrix(m02=-width / 2, m12=-height / 2),
+    ]
+    M = steps[0]
+    for step in steps[1:]:
+        M = M @ step
+    return M
+
+
 class AffineTransform(Transform):
     """transforms.py:8-68: translate @ shear @ rotate-scale @ perspective @ centre, warped with the 114 border."""
 
@@ -180,21 +205,7 @@ class AffineTransform(Transform):
                  perspective: Tuple[float, float] = (0.0, 0.0)):
         self.height, self.width, self.angle, self.scale = height, width, angle, scale
         self.translate, self.shear, self.perspective = translate, shear, perspective
-        translate_M = np.eye(3)
-        translate_M[0, 2] = translate[0] * width
-        translate_M[1, 2] = translate[1] * height
-        shear_M = np.eye(3)
-        shear_M[0, 1] = shear[0]
-        shear_M[1, 0] = shear[1]
-        rotate_scale_M = np.eye(3)
-        rotate_scale_M[:2] = rotation_matrix_2d(angle, scale)
-        perspective_M = np.eye(3)
-        perspective_M[2, 0] = perspective[0]
-        perspective_M[2, 1] = perspective[1]
-        center_M = np.eye(3)
-        center_M[0, 2] = -width / 2
-        center_M[1, 2] = -height / 2
-        self.M = translate_M @ shear_M @ rotate_scale_M @ perspective_M @ center_M
+        self.M = _compose_affine(height, width, angle, scale, translate, shear, perspective)
 
     def warp_arguments(self) -> dict:
         if any(self.perspective):
