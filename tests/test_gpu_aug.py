@@ -341,3 +341,27 @@ def test_trainer_runs_on_augmented_batches(cuda):
         losses = trainer.run_step()
         assert all(bool(torch.isfinite(v)) for v in losses.values())
     assert not torch.equal(w0, model.backbone.bottom_up.res5[0].conv1.weight.detach().float())
+
+
+def test_predictor_preprocess_on_device_equals_the_host_path(cuda):
+    """tools/inference.py Predictor: device-side resize + BGR -> RGB + CHW equals Pillow's resize of the flipped
+    image (what the reference's Predictor computes on the host, tools/inference.py:38-43), byte for byte."""
+    import os
+    import sys
+    Image = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import inference as cli
+    from yolo_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "configs", "yolov3.yaml"))
+    cfg.merge_from_list(["MODEL.WEIGHTS", "", "INPUT.MIN_SIZE_TEST", 416, "INPUT.MAX_SIZE_TEST", 608])
+    pred = cli.Predictor(cfg)
+    for h, w in [(375, 500), (480, 640), (640, 427), (416, 416), (300, 900)]:
+        bgr = _img(h, w, h + w)
+        got = pred.preprocess(bgr)
+        want = cli.resize_shortest_edge(np.ascontiguousarray(bgr[:, :, ::-1]), 416, 608).transpose(2, 0, 1)
+        assert got.dtype == torch.uint8 and got.is_cuda and tuple(got.shape) == want.shape
+        assert np.array_equal(got.cpu().numpy(), want)
+    out = pred(_img(375, 500, 1))["instances"]
+    assert out.image_size == (375, 500)

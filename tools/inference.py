@@ -54,17 +54,25 @@ class Predictor:
         self.input_format = cfg.INPUT.FORMAT
         assert self.input_format in ["RGB", "BGR"], self.input_format
 
+    def preprocess(self, original_image: np.ndarray) -> torch.Tensor:
+        """BGR HWC uint8 (host) -> the model's input, CHW uint8 on the GPU: the decoded bytes go up as they are, the
+        shortest-edge resize (Pillow's bilinear, bit for bit) and the BGR -> RGB / HWC -> CHW rearrangement are two
+        kernel launches.  The reference does all of this on the host and uploads float32 (tools/inference.py:38-43)."""
+        from yolo_amd import ops
+        from yolo_amd.data.augmentation_impl import ResizeShortestEdge
+        dev = torch.from_numpy(np.ascontiguousarray(original_image)).to(self.model.device)
+        h, w = original_image.shape[:2]
+        newh, neww = ResizeShortestEdge.get_output_shape(h, w, self.min_size, self.max_size)
+        resized = ops.aug_resample(dev, (newh, neww))
+        out = torch.empty((3, newh, neww), dtype=torch.uint8, device=dev.device)
+        ops.aug_apply([ops.aug_job(resized, out, planar=True, reverse_channels=self.input_format == "RGB")])
+        return out
+
     @torch.no_grad()
     def __call__(self, original_image: np.ndarray):
         """original_image: HWC uint8 in BGR order (OpenCV convention)."""
-        if self.input_format == "RGB":
-            original_image = original_image[:, :, ::-1]
         height, width = original_image.shape[:2]
-        image = resize_shortest_edge(np.ascontiguousarray(original_image), self.min_size, self.max_size)
-        # the reference converts to float32 on the host (tools/inference.py:42); the bytes go up as they are (a
-        # quarter of the transfer) and the stem kernel does the conversion -- same values, 0..255
-        image = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
-        return self.model([dict(height=height, width=width, image=image)])[0]
+        return self.model([dict(height=height, width=width, image=self.preprocess(original_image))])[0]
 
 
 def read_image_bgr(path: str) -> np.ndarray:
