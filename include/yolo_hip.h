@@ -295,6 +295,16 @@ int yolo_pack_conv_train_batch(const yolo_pack_desc* descs_device, int n_layers,
                                void* stream);
 
 /*
+ * One SGD-with-momentum step over flat fp32 arenas (what torch.optim.SGD does for the parameters the reference
+ * trains, tools/train_net.py via detectron2's build_optimizer: d = grad + wd * w; m = momentum * m + d; w -= lr * m,
+ * dampening 0, no Nesterov).  block_table (device): [n_blocks][3] i32 = first element, count (<= 4096), group (0 / 1)
+ * of each workgroup's run; the two groups carry their own learning rate and weight decay (weights / normalisation
+ * parameters).  A zero momentum buffer makes the first step m = d, as torch's.
+ */
+int yolo_sgd_step(float* param, const float* grad, float* momentum_buf, const int* block_table, int n_blocks, float lr0,
+                  float weight_decay0, float lr1, float weight_decay1, float momentum, void* stream);
+
+/*
  * Data gradient of a 3x3 / stride-2 / pad-1 convolution (ResidualBlock.downsample, darknet.py:79-82,113-116, under
  * autograd) in one launch, bf16: dx = yolo_conv2d_fwd(yolo_dilate2x_nhwc(dz), w_dgrad_packed) without the dilated
  * buffer and without multiplying its zeros -- every output pixel visits only the 1, 2 or 4 taps that can reach it.

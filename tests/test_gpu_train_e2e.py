@@ -425,3 +425,41 @@ def test_inference_after_training_uses_the_updated_weights(cuda):
         got = out[k].float().cpu()
         assert float((got - ref[k]).abs().max() / ref[k].abs().max()) < 1e-3, k
         assert not torch.allclose(got, before[k].float().cpu())
+
+
+def test_fused_sgd_step_equals_torch_sgd(cuda, monkeypatch):
+    """ArenaSGD's one-launch step against torch.optim.SGD's own step (YOLO_FUSED_SGD=0) from the same start over the
+    same batches: parameters and momentum buffers agree to rounding (torch may contract a + alpha * b into one
+    rounding, the kernel never does: 1e-6 relative), version counters move, the state dict keeps torch's layout."""
+    import workload
+    from yolo_amd.trainer import Trainer, synthetic_batches
+
+    def run(fused):
+        monkeypatch.setenv("YOLO_FUSED_SGD", "1" if fused else "0")
+        torch.manual_seed(0)
+        model, cfg = workload.build_model(config="yolov3.yaml", dtype="bf16",
+                                          opts=["SOLVER.IMS_PER_BATCH", 4, "SOLVER.BASE_LR", 1e-4, "SOLVER.WARMUP_ITERS", 0])
+        data = synthetic_batches(cfg, 4, 128, seed=5, device=model.device)
+        tr = Trainer(cfg, model, data, log=lambda m: None)
+        v0 = model.backbone.fpn_output0.head.weight._version
+        tr.run_step()  # compared after ONE step: later ones amplify the last-bit differences through the network
+        used = tr.optimizer._fused is not None
+        params = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+        moms = [tr.optimizer.state[p]["momentum_buffer"].detach().float().cpu().clone()
+                for g in tr.optimizer.param_groups for p in g["params"]]
+        for _ in range(2):
+            losses = tr.run_step()
+            assert all(bool(torch.isfinite(v)) for v in losses.values())
+        assert (tr.optimizer._fused is not None) == used
+        assert model.backbone.fpn_output0.head.weight._version >= v0 + 3
+        sd = tr.optimizer.state_dict()
+        assert len(sd["state"]) == 210 and all("momentum_buffer" in s for s in sd["state"].values())
+        return used, params, moms
+
+    used_f, pf, mf = run(True)
+    used_t, pt, mt = run(False)
+    assert used_f and not used_t
+    for n in pf:
+        assert torch.allclose(pf[n], pt[n], rtol=1e-5, atol=1e-7), n
+    for a, b in zip(mf, mt):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)

@@ -94,6 +94,8 @@ SIGNATURES = {
     "yolo_aug_resample_workspace_bytes": (c_size_t, [c_int, c_int]),
     "yolo_aug_apply": (c_int, [c_void_p, c_int, c_void_p]),
     "yolo_aug_resample_batch": (c_int, [c_void_p, c_int, c_void_p]),
+    "yolo_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
+                              c_void_p]),
     "yolo_conv3x3s2_dgrad": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "yolo_pack_conv_train": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,

@@ -713,6 +713,55 @@ __global__ void __launch_bounds__(256) pack_train_batch_kernel(const yolo_pack_d
 
 }  // namespace yolo
 
+// ------------------------------------------------------------------------------------------------
+// SGD with momentum over the flat parameter / gradient / momentum arenas: one launch instead of the three
+// multi-tensor passes of torch.optim.SGD (weight decay, momentum, update).  The block table says which run of up to
+// 4096 elements a workgroup owns and which of the two hyper-parameter groups (weights / normalisation) it is in.
+// ------------------------------------------------------------------------------------------------
+namespace yolo {
+struct SgdParams {
+    float* param;
+    const float* grad;
+    float* mom;
+    const int* blocks;  // [n][3]: first element, count (<= 4096), group
+    float lr[2], wd[2];
+    float momentum;
+};
+
+__global__ void __launch_bounds__(256) sgd_step_kernel(const SgdParams p) {
+    const int first = p.blocks[3 * blockIdx.x], count = p.blocks[3 * blockIdx.x + 1], g = p.blocks[3 * blockIdx.x + 2];
+    const float lr = p.lr[g], wd = p.wd[g], mu = p.momentum;
+    for (int i = threadIdx.x; i < count; i += 256) {
+        const long long e = (long long)first + i;
+        const float w = p.param[e];
+        float d = p.grad[e];
+        if (wd != 0.f) d = d + wd * w;
+        const float m = p.mom[e] * mu + d;
+        p.mom[e] = m;
+        p.param[e] = w - lr * m;
+    }
+}
+}  // namespace yolo
+
+extern "C" int yolo_sgd_step(float* param, const float* grad, float* momentum_buf, const int* block_table, int n_blocks,
+                             float lr0, float weight_decay0, float lr1, float weight_decay1, float momentum,
+                             void* stream) {
+    YOLO_REQUIRE(param && grad && momentum_buf && block_table && n_blocks > 0, "sgd_step: bad argument");
+    SgdParams p{};
+    p.param = param;
+    p.grad = grad;
+    p.mom = momentum_buf;
+    p.blocks = block_table;
+    p.lr[0] = lr0;
+    p.lr[1] = lr1;
+    p.wd[0] = weight_decay0;
+    p.wd[1] = weight_decay1;
+    p.momentum = momentum;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
 extern "C" int yolo_pack_conv_train_batch(const yolo_pack_desc* descs_device, int n_layers, int total_tiles, int dtype,
                                           void* stream) {
     YOLO_REQUIRE(descs_device && n_layers > 0 && total_tiles > 0, "pack_conv_train_batch: empty table");

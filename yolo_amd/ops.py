@@ -732,3 +732,21 @@ def aug_apply(jobs: Sequence["_lib.AugJob"]) -> None:
         return
     arr = (_lib.AugJob * n)(*jobs)
     check(lib().yolo_aug_apply(ctypes.cast(arr, ctypes.c_void_p), n, _stream()), "yolo_aug_apply")
+
+
+def sgd_block_table(segments: Sequence[Tuple[int, int, int]], device) -> Tuple[torch.Tensor, int]:
+    """Block table of ``sgd_step`` for ``segments`` = (first element, count, group) runs of the arenas."""
+    rows = []
+    for first, count, group in segments:
+        for o in range(0, count, 4096):
+            rows.append((first + o, min(4096, count - o), group))
+    return torch.tensor(rows, dtype=torch.int32, device=device).contiguous(), len(rows)
+
+
+def sgd_step(param: torch.Tensor, grad: torch.Tensor, mom: torch.Tensor, table: torch.Tensor, n_blocks: int, lr0: float,
+             wd0: float, lr1: float, wd1: float, momentum: float) -> None:
+    """SGD with momentum over the flat fp32 arenas in one launch (two hyper-parameter groups)."""
+    _require_cuda(param, "sgd_step")
+    assert param.dtype == grad.dtype == mom.dtype == torch.float32 and param.numel() == grad.numel() == mom.numel()
+    check(lib().yolo_sgd_step(_ptr(param), _ptr(grad), _ptr(mom), _ptr(table), n_blocks, lr0, wd0, lr1, wd1, momentum,
+                              _stream()), "yolo_sgd_step")

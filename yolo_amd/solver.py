@@ -1,13 +1,87 @@
 """Optimizer and learning-rate schedule of the training entry point, with detectron2's defaults for the keys the
 reference's configs set (tools/train_net.py builds both through detectron2's DefaultTrainer: SGD with momentum,
-no weight decay on normalisation parameters, WarmupMultiStepLR).  Plain torch: one fused update per step over
-parameters whose gradients the HIP backward plan produced."""
+no weight decay on normalisation parameters, WarmupMultiStepLR).  The update is one kernel over the training
+engine's flat arenas when every parameter lives there, torch's own step otherwise."""
 from __future__ import annotations
 
 from bisect import bisect_right
 from typing import List
 
 import torch
+
+
+class ArenaSGD(torch.optim.SGD):
+    """torch.optim.SGD whose step is ONE kernel launch when every parameter it updates lives in the training
+    engine's flat arenas (parameters, gradients; the momentum buffers then live in a third arena and the per-parameter
+    ``momentum_buffer`` entries of the state are views of it, so ``state_dict()`` / ``load_state_dict()`` are torch's).
+    Anything else -- parameters outside the arenas, Nesterov, dampening, a closure -- takes torch's own step."""
+
+    def __init__(self, params, model=None, **kw):
+        super().__init__(params, **kw)
+        self._model = model
+        self._fused = None  # (engine, mom arena, block table, n blocks, [(param, mom view)])
+
+    def _engine(self):
+        bb = getattr(self._model, "backbone", None)
+        return getattr(bb, "_train_engine", None)
+
+    def _prepare(self, eng):
+        groups = self.param_groups
+        if len(groups) != 2 or any(g["nesterov"] or g["dampening"] != 0 or g["maximize"] for g in groups):
+            return None
+        if groups[0]["momentum"] != groups[1]["momentum"] or groups[0]["momentum"] == 0:
+            return None
+        arena, garena = eng.param_arena, eng.grad_arena
+        base, gbase, n = arena.data_ptr(), garena.data_ptr(), arena.numel()
+        segments, views, covered = [], [], 0
+        mom = torch.zeros_like(arena)
+        for gi, g in enumerate(groups):
+            for prm in g["params"]:
+                off = (prm.data_ptr() - base) // 4
+                if prm.dtype != torch.float32 or off < 0 or off + prm.numel() > n or prm.grad is None or \
+                        prm.grad.data_ptr() != gbase + 4 * off:
+                    return None
+                # a parameter is one contiguous run of the arena, possibly permuted (conv weights are channels_last)
+                mview = torch.as_strided(mom, prm.shape, prm.stride(), off)
+                st = self.state[prm]
+                if st.get("momentum_buffer") is not None:
+                    mview.copy_(st["momentum_buffer"])
+                st["momentum_buffer"] = mview
+                segments.append((off, prm.numel(), gi))
+                views.append((prm, mview))
+                covered += prm.numel()
+        if covered != n:
+            return None
+        segments.sort()
+        from . import ops
+        table, nb = ops.sgd_block_table(segments, arena.device)
+        return eng, mom, table, nb, views
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import os
+        eng = self._engine()
+        usable = closure is None and eng is not None and eng.param_arena is not None and \
+            os.environ.get("YOLO_FUSED_SGD", "1") != "0"
+        if usable and (self._fused is None or self._fused[0] is not eng or
+                       any(self.state[p].get("momentum_buffer") is not m for p, m in self._fused[4])):
+            self._fused = self._prepare(eng)
+        if not usable or self._fused is None:
+            self._fused = None
+            return super().step(closure)
+        from . import ops
+        eng, mom, table, nb, views = self._fused
+        if any(p.grad is None for p, _ in views):
+            self._fused = None
+            return super().step(closure)
+        g0, g1 = self.param_groups
+        ops.sgd_step(eng.param_arena, eng.grad_arena, mom, table, nb, g0["lr"], g0["weight_decay"], g1["lr"],
+                     g1["weight_decay"], g0["momentum"])
+        # in-place update outside autograd's sight: move the version counters ourselves (the engines key their
+        # packed / folded weights on them)
+        ps = [p for p, _ in views]
+        torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+        return None
 
 
 def build_optimizer(cfg, model: torch.nn.Module) -> torch.optim.Optimizer:
@@ -18,7 +92,7 @@ def build_optimizer(cfg, model: torch.nn.Module) -> torch.optim.Optimizer:
         (norm_params if ".norm." in name else other).append(p)
     groups = [dict(params=other, weight_decay=cfg.SOLVER.WEIGHT_DECAY),
               dict(params=norm_params, weight_decay=cfg.SOLVER.WEIGHT_DECAY_NORM)]
-    return torch.optim.SGD(groups, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV)
+    return ArenaSGD(groups, model=model, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV)
 
 
 class WarmupMultiStepLR(torch.optim.lr_scheduler.LRScheduler):
