@@ -11,6 +11,7 @@
 // operand) and activations (MFMA B operand) share one loader and one fragment-read pattern.  With
 // channels on the MFMA row index each lane ends up holding 4 consecutive channels of one pixel,
 // which is what an NHWC epilogue wants.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -49,6 +50,22 @@ struct ConvParams {
 };
 
 constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
+
+#ifdef YOLO_CONV_TRACE
+// Phase timestamps of every workgroup of the last launch (measurement builds only): entry, first operands landed,
+// loop end, epilogue end, in 10 ns ticks of the constant clock, plus the hardware id; slots 5..8: per epilogue half,
+// tile staged in LDS / stores issued.
+constexpr int TRACE_MAX = 1 << 15;
+__device__ unsigned long long g_trace[TRACE_MAX * 10];
+#define TRACE_MARK(i)                                                                      \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < TRACE_MAX) g_trace[blockIdx.x * 10 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define TRACE_MARK(i) \
+    do {              \
+    } while (0)
+#endif
 
 // m -> (n, ho, wo).  Integer division by a run-time divisor costs ~40 instructions; for m < 2^24 a float
 // reciprocal and one correction step are exact and cost ~8.  Every lane does this for each of its tile rows in
@@ -111,6 +128,16 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TRACE_MARK(0);
+#ifdef YOLO_CONV_TRACE
+    if (tid == 0 && blockIdx.x < TRACE_MAX) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_trace[blockIdx.x * 10 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 
     // Workgroup -> tile.  Blocks b and b+8 share an XCD (private L2): give each XCD a contiguous
     // run of tiles, channel tiles of one pixel tile adjacent, so the activation tile is fetched
@@ -258,9 +285,13 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef YOLO_CONV_TRACE
+        if (s == 0) TRACE_MARK(1);
+#endif
         if (s + 1 < nsteps) stage(smem + ((s + 1) & 1) * BUF);
         compute(smem + (s & 1) * BUF);
     }
+    TRACE_MARK(2);
     // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte chunks XOR-swizzled by
     //      (pixel & 7); epilogue 2: one lane = 8 channels of one pixel, whole pixel rows leave as contiguous bytes.
     //      A tile whose f32 image would not fit the operand buffers goes through in two pixel halves (the
@@ -273,30 +304,60 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     static_assert(HP % PPP == 0, "whole passes");
     const int g = tid % G;
     const int ch_first = tile_c * TC + g * 8;
+    int prow = tid / G;  // this lane's pixel row inside a pass
+    asm volatile("" : "+v"(prow));  // keeps the epilogue's address arithmetic out of the main loop's registers
     float st_s[8], st_q[8];
     if constexpr (STATS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
     }
+    const int adv_rows = PPP / p.Wo, adv_cols = PPP - adv_rows * p.Wo;  // PPP pixels = adv_rows rows + adv_cols columns
+    const bool tiny = adv_rows + 1 > p.Ho;
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
-    // bf16 residual: all of this lane's values for the half are requested before the tile is staged, so their
-    // latency hides behind the staging instead of adding up pass by pass
-    u32x4 rres[HP / PPP];
+    // Output position of each of this lane's passes: one pixel -> (image, row, column) split for the first pass,
+    // then steps of PPP pixels with carries (a split per pass cost more than the stores themselves).  The walk is
+    // done twice, for the residual loads and for the stores, rather than kept in registers across the staging.
+    // bf16 residual: all of the lane's values for the half are requested before the tile is staged, so their
+    // latency hides behind the staging.
+    constexpr int NP = HP / PPP;
+    const int up = p.upsample ? 2 : 1;
+    const int m0 = pix_base + half * HP + prow;
+    int n0, ho0, wo0;
+    split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n0, ho0, wo0);
+    auto advance = [&](int pass, int& n, int& ho, int& wo) {  // (n, ho, wo) of pass -> of pass + 1
+        if (tiny) {  // images smaller than a pass: a step may cross several of them
+            const int m = m0 + (pass + 1) * PPP;
+            split_pixel(p, m < pix_end ? m : pix_end - 1, HoWo, n, ho, wo);
+        } else {
+            wo += adv_cols;
+            ho += adv_rows;
+            if (wo >= p.Wo) {
+                wo -= p.Wo;
+                ++ho;
+            }
+            if (ho >= p.Ho) {
+                ho -= p.Ho;
+                ++n;
+            }
+        }
+    };
+    auto res_offset = [&](int n, int ho, int wo) {
+        const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : wo;
+        return p.r_origin + (long long)n * p.r_img_stride + (long long)oh * p.r_row_stride + ow * p.r_pix_stride +
+               (long long)ch_first * (int)sizeof(T);
+    };
+    [[maybe_unused]] u32x4 rres[NP];
     if constexpr (BF) {
         if (p.res && ch_first < p.Cout) {
+            int n = n0, ho = ho0, wo = wo0;
+            const long long ro_first = res_offset(n, ho, wo);
 #pragma unroll
-            for (int pass = 0; pass < HP / PPP; ++pass) {
-                int m = pix_base + half * HP + pass * PPP + tid / G;
-                m = m < pix_end ? m : pix_end - 1;
-                int n, ho, wo;
-                split_pixel(p, m, HoWo, n, ho, wo);
-                if constexpr (S2D) {
-                    ho = 2 * ho + par_a;
-                    wo = 2 * wo + par_b;
-                }
-                rres[pass] = *(const u32x4*)(p.res + p.r_origin + (long long)n * p.r_img_stride +
-                                             (long long)ho * p.r_row_stride + wo * p.r_pix_stride + (size_t)ch_first * 2);
+            for (int pass = 0; pass < NP; ++pass) {
+                // a lane's dead passes (its last ones) re-read its first position: valid memory, value unused
+                const long long ro = m0 + pass * PPP < pix_end ? res_offset(n, ho, wo) : ro_first;
+                rres[pass] = *(const u32x4*)(p.res + ro);
+                if (pass + 1 < NP) advance(pass, n, ho, wo);
             }
         }
     }
@@ -316,25 +377,26 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         }
     }
     __syncthreads();
-    if (ch_first < p.Cout) {
+    TRACE_MARK(5 + 2 * half);
+    // the staged values are fetched GP passes at a time
+    constexpr int GP = NP % 3 == 0 ? 3 : (NP % 4 == 0 ? 4 : 1);
+    static_assert(NP % GP == 0, "whole groups of passes");
+    int n = n0, ho = ho0, wo = wo0;
 #pragma unroll
-        for (int pass = 0; pass < HP / PPP; ++pass) {
-            const int px = pass * PPP + tid / G;
-            const int m = pix_base + half * HP + px;
-            if (m >= pix_end) break;
-            int n, ho, wo;
-            split_pixel(p, m, HoWo, n, ho, wo);
-            if constexpr (S2D) {
-                ho = 2 * ho + par_a;
-                wo = 2 * wo + par_b;
-            }
-            const char* sp = smem + px * (TC * 4);
-            f32x4 v0 = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
-            f32x4 v1 = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
+    for (int g0 = 0; g0 < NP; g0 += GP) {
+    f32x4 sv0[GP], sv1[GP];
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+        const int px = (g0 + i) * PPP + prow;
+        const char* sp = smem + px * (TC * 4);
+        sv0[i] = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
+        sv1[i] = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
+    }
+#pragma unroll
+    for (int pass = g0; pass < g0 + GP; ++pass) {
+        if (m0 + pass * PPP < pix_end && ch_first < p.Cout) {
+            f32x4 v0 = sv0[pass - g0], v1 = sv1[pass - g0];
             if (p.res) {
-                [[maybe_unused]] const char* rp = p.res + p.r_origin + (long long)n * p.r_img_stride +
-                                                  (long long)ho * p.r_row_stride + wo * p.r_pix_stride +
-                                                  (size_t)ch_first * sizeof(T);
                 if constexpr (BF) {
                     const u32x4 r = rres[pass];
 #pragma unroll
@@ -345,13 +407,14 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                         v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
                     }
                 } else {
+                    const char* rp = p.res + res_offset(n, ho, wo);
                     v0 += *(const f32x4*)rp;
                     v1 += *(const f32x4*)(rp + 16);
                 }
             }
-            const int up = p.upsample ? 2 : 1;
-            char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(ho * up) * p.y_row_stride +
-                       (wo * up) * p.y_pix_stride + (size_t)ch_first * (p.y_f32 ? 4 : 2);
+            const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : wo;
+            char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(oh * up) * p.y_row_stride +
+                       (ow * up) * p.y_pix_stride + (size_t)ch_first * (p.y_f32 ? 4 : 2);
             u32x4 packed;
             if (!p.y_f32) {
                 packed[0] = pack_bf16x2(v0[0], v0[1]);
@@ -391,8 +454,15 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                 }
             }
         }
+        if (pass + 1 < NP) advance(pass, n, ho, wo);
     }
+    }  // group of passes
+    TRACE_MARK(6 + 2 * half);
     }  // half
+#ifdef YOLO_CONV_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the wave's queue
+    TRACE_MARK(3);
+#endif
     if constexpr (STATS) {
         // fold the pixel lanes of the workgroup: [which][pixel lane][channel] through LDS (the staged tile is done)
         constexpr int PL = NW * 64 / G;
@@ -419,7 +489,12 @@ template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, boo
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // two operand buffers, or the f32 epilogue staging tile if that is larger
     constexpr int OPS = 2 * (TC + TP) * ROWB, STG = TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4;
-    constexpr int LDS = OPS > STG ? OPS : STG;
+    constexpr int LDS0 = OPS > STG ? OPS : STG;
+#ifdef YOLO_CONV_TRACE
+    static const int LDS = getenv("YOLO_CONV_LONE") ? 100 * 1024 : LDS0;  // one workgroup per CU (measurement)
+#else
+    constexpr int LDS = LDS0;
+#endif
     auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -429,6 +504,23 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     const int nblocks = p.n_ctiles * p.n_ptiles;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), LDS, stream, p);
     YOLO_CHECK_HIP(hipGetLastError());
+#ifdef YOLO_CONV_TRACE
+    if (getenv("YOLO_CONV_TRACE_DUMP")) {
+        YOLO_CHECK_HIP(hipDeviceSynchronize());
+        const int n = nblocks < TRACE_MAX ? nblocks : TRACE_MAX;
+        unsigned long long* h = (unsigned long long*)malloc((size_t)n * 10 * 8);
+        YOLO_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), (size_t)n * 10 * 8));
+        FILE* f = fopen(getenv("YOLO_CONV_TRACE_DUMP"), "w");
+        if (f) {
+            fprintf(f, "# tile %dx%d nsteps %d blocks %d\n", TC, TP, p.nsteps, nblocks);
+            for (int i = 0; i < n; ++i)
+                fprintf(f, "%d %llu %llu %llu %llu %llx %llu %llu %llu %llu\n", i, h[10 * i], h[10 * i + 1], h[10 * i + 2],
+                        h[10 * i + 3], h[10 * i + 4], h[10 * i + 5], h[10 * i + 6], h[10 * i + 7], h[10 * i + 8]);
+            fclose(f);
+        }
+        free(h);
+    }
+#endif
     return YOLO_OK;
 }
 
