@@ -294,11 +294,10 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     TRACE_MARK(2);
     // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte chunks XOR-swizzled by
     //      (pixel & 7); epilogue 2: one lane = 8 channels of one pixel, whole pixel rows leave as contiguous bytes.
-    //      A tile whose f32 image would not fit the operand buffers goes through in two pixel halves (the
-    //      halves of the 2-wide pixel wave grid).
+    //      A tile whose f32 image would not fit the operand buffers goes through in two halves (each wave's first
+    //      and second half of pixel columns).
     constexpr int NH = TP * TC * 4 > 2 * BUF ? 2 : 1;
     constexpr int HP = TP / NH;
-    static_assert(NH == 1 || WP == 2, "halves follow the pixel wave grid");
     constexpr int G = TC / 8;       // 8-channel groups per pixel
     constexpr int PPP = NW * 64 / G;  // pixels per pass
     static_assert(HP % PPP == 0, "whole passes");
@@ -311,8 +310,14 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
     }
+    // A tile staged in two halves: every wave stages half of its own pixel columns in each half (all waves write,
+    // none waits), so a half holds two runs of HP/2 tile pixels, HP/2 apart: staged row s is tile pixel
+    // half * HP/2 + s (+ HP/2 from the second run on).  JUMP = that extra distance, met once per lane and half.
+    constexpr int RUN = NH == 2 ? HP / 2 : HP, JUMP = NH == 2 ? HP / 2 : 0;
+    static_assert(RUN % PPP == 0 && (NH == 1 || FP % 2 == 0), "runs of whole passes");
     const int adv_rows = PPP / p.Wo, adv_cols = PPP - adv_rows * p.Wo;  // PPP pixels = adv_rows rows + adv_cols columns
-    const bool tiny = adv_rows + 1 > p.Ho;
+    const int jmp_rows = (PPP + JUMP) / p.Wo, jmp_cols = (PPP + JUMP) - jmp_rows * p.Wo;
+    const bool tiny = jmp_rows + 1 > p.Ho;
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
     // Output position of each of this lane's passes: one pixel -> (image, row, column) split for the first pass,
@@ -322,16 +327,18 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     // latency hides behind the staging.
     constexpr int NP = HP / PPP;
     const int up = p.upsample ? 2 : 1;
-    const int m0 = pix_base + half * HP + prow;
+    const int m0 = pix_base + half * RUN + prow;
+    auto pixel_of_pass = [&](int pass) { return m0 + pass * PPP + (pass * PPP >= RUN ? JUMP : 0); };
     int n0, ho0, wo0;
     split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n0, ho0, wo0);
     auto advance = [&](int pass, int& n, int& ho, int& wo) {  // (n, ho, wo) of pass -> of pass + 1
-        if (tiny) {  // images smaller than a pass: a step may cross several of them
-            const int m = m0 + (pass + 1) * PPP;
+        if (tiny) {  // images smaller than a step: it may cross several of them
+            const int m = pixel_of_pass(pass + 1);
             split_pixel(p, m < pix_end ? m : pix_end - 1, HoWo, n, ho, wo);
         } else {
-            wo += adv_cols;
-            ho += adv_rows;
+            const bool jump = JUMP != 0 && (pass + 1) * PPP == RUN;
+            wo += jump ? jmp_cols : adv_cols;
+            ho += jump ? jmp_rows : adv_rows;
             if (wo >= p.Wo) {
                 wo -= p.Wo;
                 ++ho;
@@ -355,23 +362,30 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 // a lane's dead passes (its last ones) re-read its first position: valid memory, value unused
-                const long long ro = m0 + pass * PPP < pix_end ? res_offset(n, ho, wo) : ro_first;
+                const long long ro = pixel_of_pass(pass) < pix_end ? res_offset(n, ho, wo) : ro_first;
                 rres[pass] = *(const u32x4*)(p.res + ro);
                 if (pass + 1 < NP) advance(pass, n, ho, wo);
             }
         }
     }
     __syncthreads();
-    if (NH == 1 || wp == half) {
+    {
         const int ch0 = wc * (TC / WC) + q * 4;
-        const int px0 = (NH == 1 ? wp * (TP / WP) : 0) + l15;
+        constexpr int FPH = FP / NH;  // pixel fragment columns of a wave per half
+        const int px0 = wp * (HP / WP) + l15;
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             const int ch = ch0 + i * 16;
 #pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const int px = px0 + j * 16;
-                const f32x4 v = leaky4(acc[i][j], p.slope);
+            for (int jj = 0; jj < FPH; ++jj) {
+                const int px = px0 + jj * 16;
+                f32x4 a;
+                if constexpr (NH == 2) {  // a compile-time register choice per half, not an indexed array
+                    a = half == 0 ? acc[i][jj] : acc[i][jj + FP - FPH];
+                } else {
+                    a = acc[i][jj];
+                }
+                const f32x4 v = leaky4(a, p.slope);
                 *(f32x4*)(smem + px * (TC * 4) + (((ch >> 2) ^ (px & 7)) << 4)) = v;
             }
         }
@@ -379,7 +393,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     __syncthreads();
     TRACE_MARK(5 + 2 * half);
     // the staged values are fetched GP passes at a time
-    constexpr int GP = NP % 3 == 0 ? 3 : (NP % 4 == 0 ? 4 : 1);
+    constexpr int GP = NP <= 6 ? NP : (NP % 4 == 0 ? 4 : 1);
     static_assert(NP % GP == 0, "whole groups of passes");
     int n = n0, ho = ho0, wo = wo0;
 #pragma unroll
@@ -394,7 +408,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     }
 #pragma unroll
     for (int pass = g0; pass < g0 + GP; ++pass) {
-        if (m0 + pass * PPP < pix_end && ch_first < p.Cout) {
+        if (pixel_of_pass(pass) < pix_end && ch_first < p.Cout) {
             f32x4 v0 = sv0[pass - g0], v1 = sv1[pass - g0];
             if (p.res) {
                 if constexpr (BF) {
