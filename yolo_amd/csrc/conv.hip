@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace yolo {
@@ -331,8 +333,11 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     auto pixel_of_pass = [&](int pass) { return m0 + pass * PPP + (pass * PPP >= RUN ? JUMP : 0); };
     int n0, ho0, wo0;
     split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n0, ho0, wo0);
-    auto advance = [&](int pass, int& n, int& ho, int& wo) {  // (n, ho, wo) of pass -> of pass + 1
-        if (tiny) {  // images smaller than a step: it may cross several of them
+    // `fast`: bf16 in and out, no upsample, images not smaller than a step -- the case of nearly every launch; its
+    // passes are straight-line code (only the store itself is predicated), so the scheduler overlaps them.
+    const bool fast = BF && !tiny && !p.upsample && !p.y_f32;
+    auto advance = [&](auto fast_c, int pass, int& n, int& ho, int& wo) {  // (n, ho, wo) of pass -> of pass + 1
+        if (!decltype(fast_c)::value && tiny) {  // images smaller than a step: it may cross several of them
             const int m = pixel_of_pass(pass + 1);
             split_pixel(p, m < pix_end ? m : pix_end - 1, HoWo, n, ho, wo);
         } else {
@@ -355,17 +360,23 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                (long long)ch_first * (int)sizeof(T);
     };
     [[maybe_unused]] u32x4 rres[NP];
+    auto load_residual = [&](auto fast_c) {
+        int n = n0, ho = ho0, wo = wo0;
+        const long long ro_first = res_offset(n, ho, wo);
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            // a lane's dead passes (its last ones) re-read its first position: valid memory, value unused
+            const long long ro = pixel_of_pass(pass) < pix_end ? res_offset(n, ho, wo) : ro_first;
+            rres[pass] = *(const u32x4*)(p.res + ro);
+            if (pass + 1 < NP) advance(fast_c, pass, n, ho, wo);
+        }
+    };
     if constexpr (BF) {
         if (p.res && ch_first < p.Cout) {
-            int n = n0, ho = ho0, wo = wo0;
-            const long long ro_first = res_offset(n, ho, wo);
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                // a lane's dead passes (its last ones) re-read its first position: valid memory, value unused
-                const long long ro = pixel_of_pass(pass) < pix_end ? res_offset(n, ho, wo) : ro_first;
-                rres[pass] = *(const u32x4*)(p.res + ro);
-                if (pass + 1 < NP) advance(pass, n, ho, wo);
-            }
+            if (fast)
+                load_residual(std::true_type{});
+            else
+                load_residual(std::false_type{});
         }
     }
     __syncthreads();
@@ -395,82 +406,126 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     // the staged values are fetched GP passes at a time
     constexpr int GP = NP <= 6 ? NP : (NP % 4 == 0 ? 4 : 1);
     static_assert(NP % GP == 0, "whole groups of passes");
-    int n = n0, ho = ho0, wo = wo0;
+    auto store_passes = [&](auto fast_c, auto res_c) {
+        constexpr bool FAST = decltype(fast_c)::value, RES = decltype(res_c)::value;
+        int n = n0, ho = ho0, wo = wo0;
 #pragma unroll
-    for (int g0 = 0; g0 < NP; g0 += GP) {
-    f32x4 sv0[GP], sv1[GP];
+        for (int g0 = 0; g0 < NP; g0 += GP) {
+            f32x4 sv0[GP], sv1[GP];
 #pragma unroll
-    for (int i = 0; i < GP; ++i) {
-        const int px = (g0 + i) * PPP + prow;
-        const char* sp = smem + px * (TC * 4);
-        sv0[i] = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
-        sv1[i] = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
-    }
-#pragma unroll
-    for (int pass = g0; pass < g0 + GP; ++pass) {
-        if (pixel_of_pass(pass) < pix_end && ch_first < p.Cout) {
-            f32x4 v0 = sv0[pass - g0], v1 = sv1[pass - g0];
-            if (p.res) {
-                if constexpr (BF) {
-                    const u32x4 r = rres[pass];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        v0[2 * e] += __uint_as_float(r[e] << 16);
-                        v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
-                        v1[2 * e] += __uint_as_float(r[2 + e] << 16);
-                        v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
-                    }
-                } else {
-                    const char* rp = p.res + res_offset(n, ho, wo);
-                    v0 += *(const f32x4*)rp;
-                    v1 += *(const f32x4*)(rp + 16);
-                }
+            for (int i = 0; i < GP; ++i) {
+                const int px = (g0 + i) * PPP + prow;
+                const char* sp = smem + px * (TC * 4);
+                sv0[i] = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
+                sv1[i] = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
             }
-            const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : wo;
-            char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(oh * up) * p.y_row_stride +
-                       (ow * up) * p.y_pix_stride + (size_t)ch_first * (p.y_f32 ? 4 : 2);
-            u32x4 packed;
-            if (!p.y_f32) {
-                packed[0] = pack_bf16x2(v0[0], v0[1]);
-                packed[1] = pack_bf16x2(v0[2], v0[3]);
-                packed[2] = pack_bf16x2(v1[0], v1[1]);
-                packed[3] = pack_bf16x2(v1[2], v1[3]);
-            }
-            for (int dy = 0; dy < up; ++dy)
-                for (int dx = 0; dx < up; ++dx) {
-                    char* o = yp + dy * p.y_row_stride + dx * p.y_pix_stride;
-                    if (p.y_f32) {
-                        *(f32x4*)o = v0;
-                        *(f32x4*)(o + 16) = v1;
-                    } else {
-                        *(u32x4*)o = packed;
+#pragma unroll
+            for (int pass = g0; pass < g0 + GP; ++pass) {
+                const bool lv = pixel_of_pass(pass) < pix_end && ch_first < p.Cout;
+                f32x4 v0 = sv0[pass - g0], v1 = sv1[pass - g0];
+                const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : wo;
+                if constexpr (FAST) {
+                    if constexpr (RES) {
+                        const u32x4 r = rres[pass];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            v0[2 * e] += __uint_as_float(r[e] << 16);
+                            v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                            v1[2 * e] += __uint_as_float(r[2 + e] << 16);
+                            v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
+                        }
+                    }
+                    u32x4 packed;
+                    packed[0] = pack_bf16x2(v0[0], v0[1]);
+                    packed[1] = pack_bf16x2(v0[2], v0[3]);
+                    packed[2] = pack_bf16x2(v1[0], v1[1]);
+                    packed[3] = pack_bf16x2(v1[2], v1[3]);
+                    char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)oh * p.y_row_stride +
+                               ow * p.y_pix_stride + (size_t)ch_first * 2;
+                    if (lv) *(u32x4*)yp = packed;
+                    if constexpr (STATS) {
+                        if (lv) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float z0 = __uint_as_float(packed[e] << 16);
+                                const float z1 = __uint_as_float(packed[e] & 0xffff0000u);
+                                st_s[2 * e] += z0;
+                                st_q[2 * e] += z0 * z0;
+                                st_s[2 * e + 1] += z1;
+                                st_q[2 * e + 1] += z1 * z1;
+                            }
+                        }
+                    }
+                } else if (lv) {
+                    if (p.res) {
+                        if constexpr (BF) {
+                            const u32x4 r = rres[pass];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                v0[2 * e] += __uint_as_float(r[e] << 16);
+                                v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                                v1[2 * e] += __uint_as_float(r[2 + e] << 16);
+                                v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
+                            }
+                        } else {
+                            const char* rp = p.res + res_offset(n, ho, wo);
+                            v0 += *(const f32x4*)rp;
+                            v1 += *(const f32x4*)(rp + 16);
+                        }
+                    }
+                    char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(oh * up) * p.y_row_stride +
+                               (ow * up) * p.y_pix_stride + (size_t)ch_first * (p.y_f32 ? 4 : 2);
+                    u32x4 packed;
+                    if (!p.y_f32) {
+                        packed[0] = pack_bf16x2(v0[0], v0[1]);
+                        packed[1] = pack_bf16x2(v0[2], v0[3]);
+                        packed[2] = pack_bf16x2(v1[0], v1[1]);
+                        packed[3] = pack_bf16x2(v1[2], v1[3]);
+                    }
+                    for (int dy = 0; dy < up; ++dy)
+                        for (int dx = 0; dx < up; ++dx) {
+                            char* o = yp + dy * p.y_row_stride + dx * p.y_pix_stride;
+                            if (p.y_f32) {
+                                *(f32x4*)o = v0;
+                                *(f32x4*)(o + 16) = v1;
+                            } else {
+                                *(u32x4*)o = packed;
+                            }
+                        }
+                    if constexpr (STATS) {
+                        float z[8];
+                        if (p.y_f32) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                z[e] = v0[e];
+                                z[4 + e] = v1[e];
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                z[2 * e] = __uint_as_float(packed[e] << 16);
+                                z[2 * e + 1] = __uint_as_float(packed[e] & 0xffff0000u);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            st_s[e] += z[e];
+                            st_q[e] += z[e] * z[e];
+                        }
                     }
                 }
-            if constexpr (STATS) {
-                float z[8];
-                if (p.y_f32) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        z[e] = v0[e];
-                        z[4 + e] = v1[e];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        z[2 * e] = __uint_as_float(packed[e] << 16);
-                        z[2 * e + 1] = __uint_as_float(packed[e] & 0xffff0000u);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    st_s[e] += z[e];
-                    st_q[e] += z[e] * z[e];
-                }
+                if (pass + 1 < NP) advance(fast_c, pass, n, ho, wo);
             }
         }
-        if (pass + 1 < NP) advance(pass, n, ho, wo);
+    };
+    if (fast) {
+        if (p.res)
+            store_passes(std::true_type{}, std::true_type{});
+        else
+            store_passes(std::true_type{}, std::false_type{});
+    } else {
+        store_passes(std::false_type{}, std::false_type{});
     }
-    }  // group of passes
     TRACE_MARK(6 + 2 * half);
     }  // half
 #ifdef YOLO_CONV_TRACE
