@@ -46,6 +46,9 @@ def main():
     for name, col in zip(("prologue (entry -> first operands)", "loop", "epilogue (+ store drain)", "whole tile"), ph.T):
         q = np.percentile(col, [5, 50, 95])
         print(f"  {name:36s} mean {col.mean():7.2f}  p5 {q[0]:7.2f}  p50 {q[1]:7.2f}  p95 {q[2]:7.2f} us")
+    if len(rows[0]) >= 11:   # set-up part of the prologue
+        d = (np.array([int(r[10]) for r in rows], dtype=np.int64) - t0) / 100.0 - us[:, 0]
+        print(f"    prologue: entry -> addresses ready {d.mean():5.2f} us (p5 {np.percentile(d, 5):5.2f}, p95 {np.percentile(d, 95):5.2f})")
     if len(rows[0]) >= 10:   # epilogue sub-phases (per half: tile staged in LDS, stores issued)
         e = (np.array([[int(v) for v in r[6:10]] for r in rows], dtype=np.int64) - t0) / 100.0
         if (e[:, 2] > 0).all():

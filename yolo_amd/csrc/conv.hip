@@ -56,7 +56,7 @@ constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
 #ifdef YOLO_CONV_TRACE
 // Phase timestamps of every workgroup of the last launch (measurement builds only): entry, first operands landed,
 // loop end, epilogue end, in 10 ns ticks of the constant clock, plus the hardware id; slots 5..8: per epilogue half,
-// tile staged in LDS / stores issued.
+// tile staged in LDS / stores issued; slot 9: addresses ready, before the first operand loads are issued.
 constexpr int TRACE_MAX = 1 << 15;
 __device__ unsigned long long g_trace[TRACE_MAX * 10];
 #define TRACE_MARK(i)                                                                      \
@@ -174,15 +174,39 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         wsrc[i] = p.w + (size_t)(tile_c * TC + row) * p.w_row_bytes + schunk * 16;
     }
     const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < NXP; ++i) {
-        const int row = 8 * (wave + NW * i) + lrow;
-        int m = pix_base + row;
-        m = m < pix_end ? m : pix_end - 1;  // tail rows read a valid pixel; their results are never stored
+    {
+        // this lane's pixel rows are 8 * NW pixels apart: one pixel -> (image, row, column) split, then carried steps
+        constexpr int STEP = 8 * NW;
+        const int xs_rows = STEP / p.Wo, xs_cols = STEP - xs_rows * p.Wo;
+        const bool xtiny = xs_rows + 1 > p.Ho;  // images smaller than a step: split every row
+        const int mfirst = pix_base + 8 * wave + lrow;
         int n, ho, wo;
-        split_pixel(p, m, HoWo, n, ho, wo);
-        xsrc[i] = p.x + p.x_origin + (long long)n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
-                  (wo * p.stride) * p.x_pix_stride + (TAP2 ? (schunk & 3) : schunk) * 16;
+        split_pixel(p, mfirst < pix_end ? mfirst : pix_end - 1, HoWo, n, ho, wo);
+        const char* first = nullptr;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const char* a = p.x + p.x_origin + (long long)n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
+                            (wo * p.stride) * p.x_pix_stride + (TAP2 ? (schunk & 3) : schunk) * 16;
+            if (i == 0) first = a;
+            xsrc[i] = mfirst + STEP * i < pix_end ? a : first;  // tail rows read a valid pixel; never stored
+            if (i + 1 < NXP) {
+                if (xtiny) {
+                    const int m = mfirst + STEP * (i + 1);
+                    split_pixel(p, m < pix_end ? m : pix_end - 1, HoWo, n, ho, wo);
+                } else {
+                    wo += xs_cols;
+                    ho += xs_rows;
+                    if (wo >= p.Wo) {
+                        wo -= p.Wo;
+                        ++ho;
+                    }
+                    if (ho >= p.Ho) {
+                        ho -= p.Ho;
+                        ++n;
+                    }
+                }
+            }
+        }
     }
     const bool tapsel = (schunk >> 2) != 0;
 
@@ -283,6 +307,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 
     // ---- main loop: loads of step s+1 fly while step s is multiplied
     const int nsteps = S2D ? (1 + par_a) * (1 + par_b) * p.cpt : p.nsteps;
+    TRACE_MARK(9);
     stage(smem);
     for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -583,8 +608,8 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (f) {
             fprintf(f, "# tile %dx%d nsteps %d blocks %d\n", TC, TP, p.nsteps, nblocks);
             for (int i = 0; i < n; ++i)
-                fprintf(f, "%d %llu %llu %llu %llu %llx %llu %llu %llu %llu\n", i, h[10 * i], h[10 * i + 1], h[10 * i + 2],
-                        h[10 * i + 3], h[10 * i + 4], h[10 * i + 5], h[10 * i + 6], h[10 * i + 7], h[10 * i + 8]);
+                fprintf(f, "%d %llu %llu %llu %llu %llx %llu %llu %llu %llu %llu\n", i, h[10 * i], h[10 * i + 1], h[10 * i + 2],
+                        h[10 * i + 3], h[10 * i + 4], h[10 * i + 5], h[10 * i + 6], h[10 * i + 7], h[10 * i + 8], h[10 * i + 9]);
             fclose(f);
         }
         free(h);
