@@ -618,28 +618,30 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     return YOLO_OK;
 }
 
-// Pixel-tile choice (64, 96, 128 or 192).  Two workgroups share a CU, so a launch runs in rounds of 512 tiles; pick the pixel tile with
-// the least total tile-time (rounds x pixels per tile x relative cost per pixel).  The 192-pixel tile moves 17 %
-// fewer operand bytes per FLOP than 128 x 128 (measured 5-12 % faster per pixel on long-K layers) but pays its
-// two-half epilogue and longer prologue on short ones: only from 18 k-steps up.
+// Pixel-tile choice (64, 96, 128 or 192).  Two workgroups share a CU (three of the 64-pixel tile, 48 KB of LDS each),
+// so a launch runs in rounds of 512 (768) tiles; pick the pixel tile with the least total tile-time (rounds x pixels
+// per tile x relative cost per pixel).  The 192-pixel tile moves 17 % fewer operand bytes per FLOP than 128 x 128
+// (measured 5-12 % faster per pixel); the 64-pixel tile moves the weights once per 64 pixels and pays the per-tile
+// set-up three times as often (measured ~1.4 x the cost per pixel), but fills the chip on layers with few pixels;
+// it is only considered for 1x1 layers with K <= 512, where nothing else does.
 static int pick_tp(int M, int n_ctiles, int nsteps) {
     static const int force = getenv("YOLO_TP") ? atoi(getenv("YOLO_TP")) : 0;
     if (force == 64 || force == 96 || force == 128 || force == 192) return force;
-    // 1x1 layers with K <= 512 are bound by memory and per-tile overhead: 64-pixel tiles fit three workgroups
-    // per CU (48 KB of LDS each) and measured 2-11 % faster there
-    if (nsteps <= 8) return 64;
-    const long long slots = 512;
-    auto cost = [&](int tp, long long per_pixel) {
+    auto cost = [&](int tp, long long per_pixel, long long slots) {
         const long long tiles = (long long)((M + tp - 1) / tp) * n_ctiles;
         return ((tiles + slots - 1) / slots) * tp * per_pixel;
     };
     int best = 128;
-    long long c = cost(128, 100);
-    if (cost(96, 100) < c) {
+    long long c = cost(128, 100, 512);
+    if (cost(96, 100, 512) < c) {
         best = 96;
-        c = cost(96, 100);
+        c = cost(96, 100, 512);
     }
-    if (nsteps >= 18 && cost(192, 92) < c) best = 192;
+    if (cost(192, 92, 512) < c) {
+        best = 192;
+        c = cost(192, 92, 512);
+    }
+    if (nsteps <= 8 && cost(64, 140, 768) < c) best = 64;
     return best;
 }
 
