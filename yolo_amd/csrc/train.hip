@@ -7,6 +7,8 @@
 // the F.leaky_relu that follows it (darknet.py:59,116,120,123; fpn.py:35,69,98), the `out += residual` of
 // darknet.py:125, and their autograd backward; plus the backward of nn.Upsample(2, "nearest") (fpn.py:31,36)
 // and the zero insertion that turns the data gradient of a stride-2 convolution into a stride-1 one.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace yolo {
@@ -69,12 +71,12 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
     float s0[8], s1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
-    float sc[8], sh[8], mu[8], is[8];
+    float sc[8], sh_[8], mu[8], is[8];
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sc[e] = p.scale[g * 8 + e];
-            sh[e] = p.shift[g * 8 + e];
+            sh_[e] = p.shift[g * 8 + e];
             mu[e] = p.mean[g * 8 + e];
             is[e] = p.invstd[g * 8 + e];
         }
@@ -82,12 +84,36 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
     const long long m0 = (long long)blockIdx.x * p.chunk;
     const long long m1 = m0 + p.chunk < p.M ? m0 + p.chunk : p.M;
     const int HW = p.H * p.W;
-    // two pixels per iteration, all loads issued before the arithmetic: twice the bytes in flight per thread
-    auto addr = [&](long long m, const char* base, long long origin, long long img, int row, int pix) {
-        const int n = (int)(m / HW);
-        const int r = (int)(m - (long long)n * HW);
-        const int h = r / p.W, w = r - h * p.W;
-        return base + origin + n * img + (long long)h * row + w * pix + g * 8 * (int)sizeof(T);
+    // two pixels per iteration, all loads issued before the arithmetic: twice the bytes in flight per thread.  The two
+    // pixel positions are cursors: one (image, row, column) split each, then carried steps of 2 * PL pixels.
+    struct Cursor {
+        int n, h, w;
+    };
+    auto split = [&](long long m) {
+        Cursor c;
+        c.n = (int)(m / HW);
+        const int r = (int)(m - (long long)c.n * HW);
+        c.h = r / p.W;
+        c.w = r - c.h * p.W;
+        return c;
+    };
+    const int step = 2 * PL;
+    const int sn = step / HW, sr = step - sn * HW, sh = sr / p.W, sw = sr - sh * p.W;
+    auto advance = [&](Cursor& c) {
+        c.w += sw;
+        if (c.w >= p.W) {
+            c.w -= p.W;
+            ++c.h;
+        }
+        c.h += sh;
+        if (c.h >= p.H) {
+            c.h -= p.H;
+            ++c.n;
+        }
+        c.n += sn;
+    };
+    auto addr = [&](const Cursor& c, const char* base, long long origin, long long img, int row, int pix) {
+        return base + origin + c.n * img + (long long)c.h * row + c.w * pix + g * 8 * (int)sizeof(T);
     };
     auto accumulate = [&](const float a[8], const float z[8]) {
         if constexpr (MODE == 0) {
@@ -99,7 +125,7 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pre = z[e] * sc[e] + sh[e];
+                const float pre = z[e] * sc[e] + sh_[e];
                 const float gr = pre >= 0.f ? a[e] : a[e] * p.slope;
                 s0[e] += gr;
                 s1[e] += gr * ((z[e] - mu[e]) * is[e]);
@@ -107,22 +133,27 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const RedParams p) {
         }
     };
     long long m = m0 + pl;
-    for (; m + PL < m1; m += 2 * PL) {
-        float a0[8], a1[8], z0[8], z1[8];
-        load8<T>(addr(m, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a0);
-        load8<T>(addr(m + PL, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a1);
-        if constexpr (MODE == 1) {
-            load8<T>(addr(m, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z0);
-            load8<T>(addr(m + PL, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z1);
-        }
-        accumulate(a0, z0);
-        accumulate(a1, z1);
-    }
     if (m < m1) {
-        float a0[8], z0[8];
-        load8<T>(addr(m, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a0);
-        if constexpr (MODE == 1) load8<T>(addr(m, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z0);
-        accumulate(a0, z0);
+        Cursor c0 = split(m), c1 = split(m + PL < p.M ? m + PL : m);
+        for (; m + PL < m1; m += 2 * PL) {
+            float a0[8], a1[8], z0[8], z1[8];
+            load8<T>(addr(c0, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a0);
+            load8<T>(addr(c1, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a1);
+            if constexpr (MODE == 1) {
+                load8<T>(addr(c0, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z0);
+                load8<T>(addr(c1, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z1);
+            }
+            accumulate(a0, z0);
+            accumulate(a1, z1);
+            advance(c0);
+            advance(c1);
+        }
+        if (m < m1) {
+            float a0[8], z0[8];
+            load8<T>(addr(c0, p.a, p.a_origin, p.a_img_stride, p.a_row_stride, p.a_pix_stride), a0);
+            if constexpr (MODE == 1) load8<T>(addr(c0, p.z, p.z_origin, p.z_img_stride, p.z_row_stride, p.z_pix_stride), z0);
+            accumulate(a0, z0);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -249,21 +280,43 @@ struct ApplyParams {
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const ApplyParams p) {
     const int HW = p.H * p.W;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % p.G);
-        const long long m = i / p.G;
-        const int n = (int)(m / HW);
-        const int rr = (int)(m - (long long)n * HW);
-        const int h = rr / p.W, w = rr - h * p.W;
+    // per-channel terms of one 8-channel group (k1 = dbeta / M, k2 = dgamma / M in the backward form)
+    struct Terms {
+        float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+    };
+    auto load_terms = [&](int g, Terms& t) {
+        const f32x4 sc0 = *(const f32x4*)(p.scale + g * 8), sc1 = *(const f32x4*)(p.scale + g * 8 + 4);
+        const f32x4 sh0 = *(const f32x4*)(p.shift + g * 8), sh1 = *(const f32x4*)(p.shift + g * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t.sc[e] = sc0[e];
+            t.sc[4 + e] = sc1[e];
+            t.sh[e] = sh0[e];
+            t.sh[4 + e] = sh1[e];
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 mu = *(const f32x4*)(p.mean + g * 8 + 4 * h), is = *(const f32x4*)(p.invstd + g * 8 + 4 * h);
+                const f32x4 db = *(const f32x4*)(p.dbeta + g * 8 + 4 * h), dg = *(const f32x4*)(p.dgamma + g * 8 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t.mu[4 * h + e] = mu[e];
+                    t.is[4 * h + e] = is[e];
+                    t.k1[4 * h + e] = db[e] * p.inv_count;
+                    t.k2[4 * h + e] = dg[e] * p.inv_count;
+                }
+            }
+        }
+    };
+    auto one = [&](const Terms& t, int g, int n, int h, int w) {
         const int cb = g * 8 * (int)sizeof(T);
         float z[8], o[8];
         load8<T>(p.z + p.z_origin + n * p.z_img_stride + (long long)h * p.z_row_stride + w * p.z_pix_stride + cb, z);
-        const f32x4 sc0 = *(const f32x4*)(p.scale + g * 8), sc1 = *(const f32x4*)(p.scale + g * 8 + 4);
-        const f32x4 sh0 = *(const f32x4*)(p.shift + g * 8), sh1 = *(const f32x4*)(p.shift + g * 8 + 4);
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pre = z[e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                const float pre = z[e] * t.sc[e] + t.sh[e];
                 o[e] = pre >= 0.f ? pre : pre * p.slope;
             }
             if (p.r) {
@@ -277,15 +330,55 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const ApplyParams p) {
             load8<T>(p.r + p.r_origin + n * p.r_img_stride + (long long)h * p.r_row_stride + w * p.r_pix_stride + cb, dy);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int c = g * 8 + e;
-                const float sc = e < 4 ? sc0[e & 3] : sc1[e & 3];
-                const float pre = z[e] * sc + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                const float pre = z[e] * t.sc[e] + t.sh[e];
                 const float gr = pre >= 0.f ? dy[e] : dy[e] * p.slope;
-                const float zh = (z[e] - p.mean[c]) * p.invstd[c];
-                o[e] = sc * (gr - p.dbeta[c] * p.inv_count - zh * p.dgamma[c] * p.inv_count);
+                const float zh = (z[e] - t.mu[e]) * t.is[e];
+                o[e] = t.sc[e] * (gr - t.k1[e] - zh * t.k2[e]);
             }
         }
         store8<T>(p.y + p.y_origin + n * p.y_img_stride + (long long)h * p.y_row_stride + w * p.y_pix_stride + cb, o);
+    };
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (256 % p.G == 0) {
+        // The grid's stride is a whole number of pixels: a thread keeps its channel group (per-channel terms loaded
+        // once) and walks the pixels in equal steps: one (image, row, column) split, then carried additions.
+        if (i >= p.total) return;
+        const int g = (int)(i % p.G);
+        Terms t;
+        load_terms(g, t);
+        long long m = i / p.G;
+        const long long step = stride / p.G, M = p.total / p.G;
+        int n = (int)(m / HW);
+        const int rr = (int)(m - (long long)n * HW);
+        int h = rr / p.W, w = rr - h * p.W;
+        const int sn = (int)(step / HW), sr = (int)(step - (long long)sn * HW);
+        const int sh = sr / p.W, sw = sr - sh * p.W;
+        for (; m < M; m += step) {
+            one(t, g, n, h, w);
+            w += sw;
+            if (w >= p.W) {
+                w -= p.W;
+                ++h;
+            }
+            h += sh;
+            if (h >= p.H) {
+                h -= p.H;
+                ++n;
+            }
+            n += sn;
+        }
+        return;
+    }
+    for (; i < p.total; i += stride) {
+        const int g = (int)(i % p.G);
+        const long long m = i / p.G;
+        const int n = (int)(m / HW);
+        const int rr = (int)(m - (long long)n * HW);
+        const int h = rr / p.W, w = rr - h * p.W;
+        Terms t;
+        load_terms(g, t);
+        one(t, g, n, h, w);
     }
 }
 
