@@ -276,22 +276,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+                    // x on the MFMA row index: a lane ends with 4 consecutive input channels of one output channel,
+                    // which are 16 contiguous bytes of dW
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     }
 
-    // ---- partial tile -> this split's slab
+    // ---- partial tile -> this split's slab, 16 bytes per store
     float* out = p.out + (long long)split * p.slab;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        const int co = mt * 128 + wm * 16 * FM + i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ci = nt * 128 + wn * 64 + j * 16 + l15;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = mt * 128 + wm * 16 * FM + i * 16 + 4 * g + e;
-                if (co < p.Cout && ci < p.Cin) out[((long long)co * p.taps + tap) * p.Cin + ci] = acc[i][j][e];
-            }
+            const int ci = nt * 128 + wn * 64 + j * 16 + 4 * g;
+            if (co < p.Cout && ci < p.Cin) *(f32x4*)(out + ((long long)co * p.taps + tap) * p.Cin + ci) = acc[i][j];
         }
     }
 }
