@@ -622,14 +622,17 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 // so a launch runs in rounds of 512 (768) tiles; pick the pixel tile with the least total tile-time (rounds x pixels
 // per tile x relative cost per pixel).  The 192-pixel tile moves 17 % fewer operand bytes per FLOP than 128 x 128
 // (measured 5-12 % faster per pixel); the 64-pixel tile moves the weights once per 64 pixels and pays the per-tile
-// set-up three times as often (measured ~1.4 x the cost per pixel), but fills the chip on layers with few pixels;
+// set-up three times as often (measured ~1.5 x the cost per pixel), but fills the chip on layers with few pixels;
 // it is only considered for 1x1 layers with K <= 512, where nothing else does.
 static int pick_tp(int M, int n_ctiles, int nsteps) {
     static const int force = getenv("YOLO_TP") ? atoi(getenv("YOLO_TP")) : 0;
     if (force == 64 || force == 96 || force == 128 || force == 192) return force;
     auto cost = [&](int tp, long long per_pixel, long long slots) {
         const long long tiles = (long long)((M + tp - 1) / tp) * n_ctiles;
-        return ((tiles + slots - 1) / slots) * tp * per_pixel;
+        // in sixteenths of a round: whole rounds while there are few (the resident tiles run in lock-step); from
+        // three rounds on the slots drift apart and the tail costs about half a round
+        const long long r16 = tiles >= 3 * slots ? (16 * tiles + slots - 1) / slots + 8 : 16 * ((tiles + slots - 1) / slots);
+        return r16 * tp * per_pixel;
     };
     int best = 128;
     long long c = cost(128, 100, 512);
@@ -641,7 +644,7 @@ static int pick_tp(int M, int n_ctiles, int nsteps) {
         best = 192;
         c = cost(192, 92, 512);
     }
-    if (nsteps <= 8 && cost(64, 140, 768) < c) best = 64;
+    if (nsteps <= 8 && cost(64, 150, 768) < c) best = 64;
     return best;
 }
 
