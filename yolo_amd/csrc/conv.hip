@@ -358,9 +358,10 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     auto pixel_of_pass = [&](int pass) { return m0 + pass * PPP + (pass * PPP >= RUN ? JUMP : 0); };
     int n0, ho0, wo0;
     split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n0, ho0, wo0);
-    // `fast`: bf16 in and out, no upsample, images not smaller than a step -- the case of nearly every launch; its
+    // `fast`: bf16 in, no upsample, images not smaller than a step (and bf16 out, or f32 out without residual: the
+    // head tensors) -- the case of nearly every launch; its
     // passes are straight-line code (only the store itself is predicated), so the scheduler overlaps them.
-    const bool fast = BF && !tiny && !p.upsample && !p.y_f32;
+    const bool fast = BF && !tiny && !p.upsample;
     auto advance = [&](auto fast_c, int pass, int& n, int& ho, int& wo) {  // (n, ho, wo) of pass -> of pass + 1
         if (!decltype(fast_c)::value && tiny) {  // images smaller than a step: it may cross several of them
             const int m = pixel_of_pass(pass + 1);
@@ -431,8 +432,8 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     // the staged values are fetched GP passes at a time
     constexpr int GP = NP <= 6 ? NP : (NP % 4 == 0 ? 4 : 1);
     static_assert(NP % GP == 0, "whole groups of passes");
-    auto store_passes = [&](auto fast_c, auto res_c) {
-        constexpr bool FAST = decltype(fast_c)::value, RES = decltype(res_c)::value;
+    auto store_passes = [&](auto fast_c, auto res_c, auto f32out_c) {
+        constexpr bool FAST = decltype(fast_c)::value, RES = decltype(res_c)::value, YF = decltype(f32out_c)::value;
         int n = n0, ho = ho0, wo = wo0;
 #pragma unroll
         for (int g0 = 0; g0 < NP; g0 += GP) {
@@ -460,15 +461,22 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                             v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
                         }
                     }
-                    u32x4 packed;
-                    packed[0] = pack_bf16x2(v0[0], v0[1]);
-                    packed[1] = pack_bf16x2(v0[2], v0[3]);
-                    packed[2] = pack_bf16x2(v1[0], v1[1]);
-                    packed[3] = pack_bf16x2(v1[2], v1[3]);
                     char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)oh * p.y_row_stride +
-                               ow * p.y_pix_stride + (size_t)ch_first * 2;
-                    if (lv) *(u32x4*)yp = packed;
-                    if constexpr (STATS) {
+                               ow * p.y_pix_stride + (size_t)ch_first * (YF ? 4 : 2);
+                    [[maybe_unused]] u32x4 packed;
+                    if constexpr (YF) {  // f32 output (the head tensors)
+                        if (lv) {
+                            *(f32x4*)yp = v0;
+                            *(f32x4*)(yp + 16) = v1;
+                        }
+                    } else {
+                        packed[0] = pack_bf16x2(v0[0], v0[1]);
+                        packed[1] = pack_bf16x2(v0[2], v0[3]);
+                        packed[2] = pack_bf16x2(v1[0], v1[1]);
+                        packed[3] = pack_bf16x2(v1[2], v1[3]);
+                        if (lv) *(u32x4*)yp = packed;
+                    }
+                    if constexpr (STATS && !YF) {
                         if (lv) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -543,13 +551,15 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             }
         }
     };
-    if (fast) {
+    if (fast && !p.y_f32) {
         if (p.res)
-            store_passes(std::true_type{}, std::true_type{});
+            store_passes(std::true_type{}, std::true_type{}, std::false_type{});
         else
-            store_passes(std::true_type{}, std::false_type{});
+            store_passes(std::true_type{}, std::false_type{}, std::false_type{});
+    } else if (!STATS && fast && !p.res) {
+        store_passes(std::true_type{}, std::false_type{}, std::true_type{});
     } else {
-        store_passes(std::false_type{}, std::false_type{});
+        store_passes(std::false_type{}, std::false_type{}, std::false_type{});
     }
     TRACE_MARK(6 + 2 * half);
     }  // half
