@@ -14,6 +14,8 @@ What is fused away relative to the reference's eager graph (all citations: refer
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -85,6 +87,9 @@ class Yolov3Engine:
         self._packed: Dict[str, PackedConv] = {}
         self._plans: Dict[Tuple[int, int, int, int], Plan] = {}
         self._in_hw: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._side = None
+        self._dstream = None
+        self.nms_on_side_stream = os.environ.get("YOLO_NMS_STREAM", "1") != "0"
         self.repack()
 
     # ------------------------------------------------------------------ weights
@@ -250,12 +255,20 @@ class Yolov3Engine:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         P = self.plan(N, padded_hw[0], padded_hw[1], slot)
         self.run_backbone(images, mean, std, padded_hw, plan=P)
-        cand = self.decode(P, score_thr)
-        if P.total_host is None:
-            P.total_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        P.total_host.copy_(cand.img_offsets[N:N + 1], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # The decode launches (small, latency-bound) go to their own stream behind the batch's last convolution, so
+        # the next batch's convolutions follow this batch's directly on the main stream.  The head tensors of this
+        # slot are not written again before finish() has waited for the decode on the host.
+        main = torch.cuda.current_stream(self.device)
+        dstream = self._decode_stream() if self.nms_on_side_stream else main
+        if dstream is not main:
+            dstream.wait_stream(main)
+        with torch.cuda.stream(dstream):
+            cand = self.decode(P, score_thr)
+            if P.total_host is None:
+                P.total_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            P.total_host.copy_(cand.img_offsets[N:N + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         return InFlight(P, cand, ev, score_thr, (N, Hs, Ws))
 
     def finish(self, h: "InFlight", *, nms_thr: float, max_det: int = 100, nms_mode: int = ops.NMS_AUTO,
@@ -271,24 +284,47 @@ class Yolov3Engine:
             cand = self.decode(P, h.score_thr, cap=int(total * 1.25) + 1024)
             total = int(cand.img_offsets[P.N].item())
         dev = self.device
-        if P.keep is None or P.keep.shape[1] != max_det:
-            P.keep = torch.empty((P.N, max_det), dtype=torch.int32, device=dev)
-            P.n_keep = torch.empty((P.N,), dtype=torch.int32, device=dev)
-        if total > 0:
-            need = ops.nms_workspace_bytes(P.N, total)
-            if P.nms_ws is None or P.nms_ws.numel() < need:
-                P.nms_ws = torch.empty(int(need * 1.5), dtype=torch.uint8, device=dev)
-        ops.batched_nms(cand.boxes, cand.scores, cand.classes, cand.img_offsets, total, nms_thr,
-                        num_classes=self.num_classes, mode=nms_mode, auto_limit=auto_limit, top_k=max_det,
-                        keep_stride=max_det, workspace=P.nms_ws, keep=P.keep, n_keep=P.n_keep)
-        N, Hs, Ws = h.geom
-        if in_hw is None:  # same stored size for the whole batch: cached, no host-to-device copy per call
-            if h.geom not in self._in_hw:
-                self._in_hw[h.geom] = torch.tensor([[Hs, Ws]] * N, dtype=torch.int32, device=dev)
-            in_hw = self._in_hw[h.geom]
-        if out_hw is None:
-            out_hw = in_hw
-        return ops.gather_detections(cand, P.keep, P.n_keep, in_hw, out_hw)
+        # NMS + gather go to a side stream: a dozen launch-bound kernels that would otherwise sit between two
+        # batches' convolutions on the main stream.  Their inputs are complete (the host has just waited for the
+        # batch's decode); the main stream waits for them before it goes on, which orders both the caller's use of
+        # the result and the next reuse of this slot's candidate buffers -- at that point the main stream is still
+        # busy with the convolutions queued by the following submit(), so the wait costs nothing.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream() if self.nms_on_side_stream else main
+        with torch.cuda.stream(side):
+            if P.keep is None or P.keep.shape[1] != max_det:
+                P.keep = torch.empty((P.N, max_det), dtype=torch.int32, device=dev)
+                P.n_keep = torch.empty((P.N,), dtype=torch.int32, device=dev)
+            if total > 0:
+                need = ops.nms_workspace_bytes(P.N, total)
+                if P.nms_ws is None or P.nms_ws.numel() < need:
+                    P.nms_ws = torch.empty(int(need * 1.5), dtype=torch.uint8, device=dev)
+            ops.batched_nms(cand.boxes, cand.scores, cand.classes, cand.img_offsets, total, nms_thr,
+                            num_classes=self.num_classes, mode=nms_mode, auto_limit=auto_limit, top_k=max_det,
+                            keep_stride=max_det, workspace=P.nms_ws, keep=P.keep, n_keep=P.n_keep)
+            N, Hs, Ws = h.geom
+            if in_hw is None:  # same stored size for the whole batch: cached, no host-to-device copy per call
+                if h.geom not in self._in_hw:
+                    self._in_hw[h.geom] = torch.tensor([[Hs, Ws]] * N, dtype=torch.int32, device=dev)
+                in_hw = self._in_hw[h.geom]
+            if out_hw is None:
+                out_hw = in_hw
+            det, n_det = ops.gather_detections(cand, P.keep, P.n_keep, in_hw, out_hw)
+        if side is not main:
+            main.wait_stream(side)
+            det.record_stream(main)
+            n_det.record_stream(main)
+        return det, n_det
+
+    def _decode_stream(self):
+        if self._dstream is None:
+            self._dstream = torch.cuda.Stream(self.device)
+        return self._dstream
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
     def detect(self, images: torch.Tensor, *, score_thr: float, nms_thr: float, mean, std,
                padded_hw=None, max_det: int = 100, nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000,
