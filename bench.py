@@ -81,8 +81,8 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
               + c.out_channels * c.in_channels * c.kernel_size ** 2 * es
               + plan.N * meta["y"].H * meta["y"].W * c.out_channels * meta["y"].buf.element_size()
               + (M * c.out_channels * es if meta["residual"] is not None else 0))
-        timed.append((i, tp, 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2, by))
-    which = {i: k for k, (i, _, _, _) in enumerate(timed)}
+        timed.append((i, tp, 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2, by, c.kernel_size))
+    which = {i: k for k, (i, _, _, _, _) in enumerate(timed)}
     ms = [0.0] * len(timed)
     empty = 0.0
     for _ in range(passes):
@@ -103,13 +103,13 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
         empty += e0.elapsed_time(e1) / passes
         for k, (a, b) in enumerate(pairs):
             ms[k] += a.elapsed_time(b) / passes
-    acc = {}
-    for (i, tp, fl, by), t in zip(timed, ms):
-        a = acc.setdefault(tp, [0.0, 0.0, 0, 0.0])
-        a[0] += fl
-        a[1] += max(t - empty, 1e-6)
-        a[2] += 1
-        a[3] += by
+    acc, by_k = {}, {}
+    for (i, tp, fl, by, ks), t in zip(timed, ms):
+        for a in (acc.setdefault(tp, [0.0, 0.0, 0, 0.0]), by_k.setdefault((tp, ks), [0.0, 0.0, 0, 0.0])):
+            a[0] += fl
+            a[1] += max(t - empty, 1e-6)
+            a[2] += 1
+            a[3] += by
     dom = max(acc, key=lambda tp: acc[tp][1])
     flops, t_ms, launches, by = acc[dom]
     achieved = flops / (t_ms * 1e-3) / 1e12
@@ -126,6 +126,12 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
         if hit:
             out["traffic"] = hit["hbm_bytes_per_launch"]
             out["traffic_source"] = "profiles/pmc_traffic.json: " + rec.get("source", "")
+    # the same instance serves long-K (3x3, matrix-bound) and short-K (1x1, memory-bound) layers: both parts of its time
+    out["by_filter_size"] = {
+        f"{ks}x{ks}": dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
+                           avg_launch_us=round(a[1] * 1e3 / a[2], 2),
+                           algorithmic_gbytes_per_s=round(a[3] / (a[1] * 1e-3) / 1e9))
+        for (tp, ks), a in sorted(by_k.items()) if tp == dom}
     out["other_instances"] = {
         f"128x{tp}": dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
                           avg_launch_us=round(a[1] * 1e3 / a[2], 2))
