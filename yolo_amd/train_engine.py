@@ -113,6 +113,8 @@ class TrainEngine:
         self._wcache: Dict[str, tuple] = {}
         self._wbufs: Dict[str, tuple] = {}
         self._zero_bias: Dict[int, torch.Tensor] = {}
+        self._wstream = None
+        self.wgrad_on_side_stream = os.environ.get("YOLO_WGRAD_STREAM", "1") != "0"
         self.bucket_bytes = 64 << 20
         self.process_group = None
         self.fuse_bn_sums = os.environ.get("YOLO_FUSE_BN_SUMS", "1") != "0"
@@ -455,6 +457,8 @@ class TrainEngine:
                 from .utils.dist import GradBucketer
                 P.bucketer = GradBucketer(P.arena, self.bucket_bytes, self.process_group)
             P.bucketer.start()
+        main = torch.cuda.current_stream(self.device)
+        side = self._wgrad_stream() if self.wgrad_on_side_stream else main
         for L in reversed(P.layers):
             if L.frozen:
                 continue
@@ -470,9 +474,17 @@ class TrainEngine:
                     ops.sum2x2(L.up_src, L.dy)
                 ops.bn_act_bwd(L.dy, L.z, L.stats, L.dz, L.dgamma, L.dbeta, P.bn_ws, slope=L.slope)
             dz = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, (c.out_channels + 7) // 8 * 8, 0)
-            ops.conv2d_wgrad(L.x, dz, L.dW, P.wg_ws, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride)
-            if ddp:
-                P.bucketer.ready(L.arena_end)  # this layer's gradients are final: maybe launch a bucket
+            # The weight gradient only feeds the optimizer: it runs on a stream of its own, next to the data gradient
+            # and the memory-bound BatchNorm backward of the following layers (it reads x and dz, which nothing
+            # overwrites during backward, and shares its workspace only with the other weight gradients, which
+            # the side stream keeps in order).
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(L.x, dz, L.dW, P.wg_ws, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size,
+                                 stride=c.stride)
+                if ddp:
+                    P.bucketer.ready(L.arena_end)  # this layer's gradients are final: maybe launch a bucket
             if L.dx is None:
                 continue
             w, b = self._packed(L.name, "dgrad")
@@ -486,8 +498,15 @@ class TrainEngine:
                 ops.dilate2x(src, L.dzd)
                 src = L.dzd
             ops.conv2d_fwd(src, w, b, L.dx, cin=cpad, cout=c.in_channels, k=c.kernel_size, stride=1, slope=1.0, residual=res)
+        if side is not main:
+            main.wait_stream(side)
         if ddp:
             P.bucketer.finish()
+
+    def _wgrad_stream(self):
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(self.device)
+        return self._wstream
 
     def param_grads(self, P: TPlan) -> Dict[str, torch.Tensor]:
         """name -> gradient in the parameter's own layout ([Cout, Cin, k, k] views of the f32 buffers)."""
