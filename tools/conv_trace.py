@@ -1,5 +1,6 @@
-"""Phase timing of the convolution kernel's workgroups (needs a library built with -DYOLO_CONV_TRACE, selected with
-YOLO_HIP_LIB): where a launch's time goes between kernel entry, first operands landed, loop end and epilogue end.
+"""Phase timing of the convolution kernel's workgroups (needs a library built with -DYOLO_CONV_TRACE -- `make -C
+yolo_amd/csrc trace` -- selected with YOLO_HIP_LIB): where a launch's time goes between kernel entry, first operands
+landed, loop end and epilogue end.  YOLO_CONV_LONE=1: one workgroup per CU.
 usage: YOLO_HIP_LIB=yolo_amd/libyolo_hip_trace.so python tools/conv_trace.py CIN COUT K STRIDE H [N=64] [RES=0]"""
 import os
 import sys
