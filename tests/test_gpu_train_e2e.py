@@ -463,3 +463,26 @@ def test_fused_sgd_step_equals_torch_sgd(cuda, monkeypatch):
         assert torch.allclose(pf[n], pt[n], rtol=1e-5, atol=1e-7), n
     for a, b in zip(mf, mt):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_side_stream_weight_gradients_equal_the_single_stream_ones(cuda):
+    """Backward with the weight gradients on their own stream (the default) gives bit for bit the gradients of
+    backward on one stream: same kernels, the streams only reorder independent launches -- a missing wait between
+    them would show up here."""
+    model, cfg, sd, imgs, gb, gc, inputs = _make("bf16", N=4, S=160)
+    model.train()
+    eng = model.backbone.train_engine()
+    grads = {}
+    for side in (True, False, True):
+        eng.wgrad_on_side_stream = side
+        model.zero_grad(set_to_none=True)
+        losses = model(inputs)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        got = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert len(got) == 210
+        if not grads:
+            grads = got
+            continue
+        for n in grads:
+            assert torch.equal(got[n], grads[n]), (side, n)
