@@ -233,8 +233,9 @@ def test_benchmark_size_properties(cuda):
 
 
 def test_side_stream_postprocessing_equals_single_stream(cuda, calibrated):
-    """Decode and NMS + gather on their own streams (the default) return bit for bit what one stream returns, in
-    the pipelined mode too, where consecutive batches reuse the two sets of buffers."""
+    """Decode, NMS + gather and the coarse levels' output branches on their own streams (the default) return bit
+    for bit what one stream returns, in the pipelined mode too, where consecutive batches reuse the two sets of
+    buffers."""
     model, cfg, sd = calibrated
     model.backbone.compute_dtype = torch.bfloat16
     eng = model.backbone.engine()
@@ -242,13 +243,13 @@ def test_side_stream_postprocessing_equals_single_stream(cuda, calibrated):
     batches = [workload.synthetic_images(3, 128, 160, seed=20 + i, device=cuda) for i in range(5)]
     results = {}
     for side in (True, False):
-        eng.nms_on_side_stream = side
+        eng.nms_on_side_stream = eng.branch_on_side_stream = side
         outs = []
         for det, n_det in eng.detect_pipelined(iter(batches), score_thr=0.05, nms_thr=0.5, mean=mean, std=std, max_det=100):
             outs.append((det.clone(), n_det.clone()))
         torch.cuda.synchronize()
         results[side] = outs
-    eng.nms_on_side_stream = True
+    eng.nms_on_side_stream = eng.branch_on_side_stream = True
     assert len(results[True]) == len(batches)
     assert sum(int(n.sum()) for _, n in results[True]) > 0
     for (d0, n0), (d1, n1) in zip(results[True], results[False]):

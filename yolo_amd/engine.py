@@ -89,6 +89,8 @@ class Yolov3Engine:
         self._in_hw: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._side = None
         self._dstream = None
+        self._bstream = None
+        self.branch_on_side_stream = os.environ.get("YOLO_BRANCH_STREAM", "1") != "0"
         self.nms_on_side_stream = os.environ.get("YOLO_NMS_STREAM", "1") != "0"
         self.repack()
 
@@ -215,8 +217,25 @@ class Yolov3Engine:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         P = plan if plan is not None else self.plan(N, padded_hw[0], padded_hw[1])
         self.run_backbone_prefix(images, mean, std, P)
-        for step in P.steps:
-            step()
+        if not self.branch_on_side_stream:
+            for step in P.steps:
+                step()
+            return P
+        # The output branches of the two coarse levels (3x3 conv + head conv, fpn.py:96-100) depend only on their
+        # level's lateral block and write buffers nothing else touches: they run on a stream of their own next to
+        # the upsample conv and the next level's lateral block (few-tile layers that leave CUs idle on their own).
+        main = torch.cuda.current_stream(self.device)
+        side = self._branch_stream()
+        for meta, step in zip(P.meta, P.steps):
+            name = meta["name"]
+            if name.startswith(("fpn_output0.", "fpn_output1.")):
+                if name.endswith(".conv"):
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    step()
+            else:
+                step()
+        main.wait_stream(side)
         return P
 
     def run_backbone_prefix(self, images: torch.Tensor, mean, std, P: Plan) -> None:
@@ -320,6 +339,11 @@ class Yolov3Engine:
         if self._dstream is None:
             self._dstream = torch.cuda.Stream(self.device)
         return self._dstream
+
+    def _branch_stream(self):
+        if self._bstream is None:
+            self._bstream = torch.cuda.Stream(self.device)
+        return self._bstream
 
     def _side_stream(self):
         if self._side is None:
