@@ -139,7 +139,7 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
     return out
 
 
-def _cpu_baseline(model, cfg, n_images: int = 8, reps: int = 2):
+def _cpu_baseline(model, cfg, n_images: int = 16, reps: int = 14):
     """The CPU oracle (plain torch fp32 restatement of the reference + C NMS) on a bounded sample of the
     same workload, timed on this box's host cores."""
     import workload
