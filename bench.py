@@ -1,24 +1,31 @@
 """Headline benchmark: images/sec of YOLOv3-416 inference including head decode + NMS on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no WORLD_SIZE in the environment, this process starts N fresh rank processes itself (one per GPU,
+RCCL) BEFORE it touches the GPU, relays rank 0's output and exits with the worst exit code -- the way the
+reference's ``launch(main, num_gpus, ...)`` starts its ranks (tools/train_net.py:140-147).  Started under
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (WORLD_SIZE set) it is one rank.
 
 One "step" = one pass of the hot path (fused stem -> Darknet-53 -> FPN -> heads -> decode -> batched NMS
 -> top-100 gather) over one resident batch of 64 synthetic uint8 images per GPU.  Steps run in the engine's
-throughput mode (two sets of activation buffers: the host reads step i's candidate count while step i+1's
-convolutions are already queued); all K steps, including the last one's NMS, finish inside the timed region.  Images shard across
-GPUs with no data-path collective (weak scaling); the only collectives are the barriers and the MAX over
-ranks of the timed region.  Rank 0 prints one JSON line.
+throughput mode; all timed steps, including the last one's NMS, finish inside the timed region.  Images shard across
+GPUs with no data-path collective (weak scaling); the only collectives are the barriers and the MAX over ranks of
+the timed region.  K steps at 5 ms are too short a region to compare boxes (box-to-box spread is a few per cent), so
+the K steps are repeated back to back until the region is at least ``--min-seconds`` long and the time is divided by
+the number of steps actually run (``timed_steps``).  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -26,62 +33,172 @@ sys.path.insert(0, ROOT)
 BATCH = 64
 SIZE = 416
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak for bf16 on MI355X
+PEAK_HBM_GBS = 8000.0
 
 
-def _dist_setup(n_gpus: int):
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # YOLO_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
-    # (ranks then share cards); the measured configuration is always nccl (= RCCL), one rank per GPU.
-    backend = os.environ.get("YOLO_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local %= torch.cuda.device_count()
-    torch.cuda.set_device(local if world > 1 else 0)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend=backend)
-    return world, rank, local
+# ------------------------------------------------------------------------------------------------------------
+# launcher: N ranks from one command
+# ------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def _barrier(world: int):
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
+def launch_ranks(n: int, argv) -> int:
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and
+    wait for them.  The parent never initialises the GPU.  Returns the worst exit code."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(_free_port())
+    env["WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    worst = 0
+    deadline = time.time() + float(os.environ.get("YOLO_BENCH_RANK_TIMEOUT", "900"))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:  # a rank died: the others would wait for it in a collective for ever
+                    q.terminate()
+        if alive and time.time() > deadline:
+            worst = worst or 124
+            for q in alive:
+                q.kill()
+        time.sleep(0.05)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the measured workload
+# ------------------------------------------------------------------------------------------------------------
+class Yolov3Inference:
+    """Batch-64 YOLOv3-416 bf16 inference on this rank's GPU.  (Any object with these methods can be benchmarked:
+    YOLO_BENCH_WORKLOAD=module:factory replaces it -- the CPU tests of the launcher use a stub.)"""
+
+    metric = "images/sec YOLOv3-416 inference incl. decode+NMS"
+    unit = "images/sec"
+    dtype = "bf16"
+    data = "synthetic"
+    units_per_step = BATCH
+
+    def __init__(self, rank: int, world: int, local: int):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
+        backend = os.environ.get("YOLO_BENCH_BACKEND", "nccl")
+        if backend != "nccl":  # rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks
+            local %= torch.cuda.device_count()
+        torch.cuda.set_device(local if world > 1 else 0)
+        self.torch = torch
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def prepare(self):
+        import workload
+        torch = self.torch
+        self.model, self.cfg = workload.calibrated_model(size=SIZE, calib_batch=4, config="yolov3-aug.yaml", dtype="bf16",
+                                                         head_dtype="f32", device=str(self.device))
+        self.eng = self.model.backbone.engine()
+        # every rank gets its own shard of images (different seeds), already resident in HBM
+        self.imgs = workload.synthetic_images(BATCH, SIZE, SIZE, seed=1 + self.rank, device=self.model.device)
+        cfg = self.cfg
+        self.mean, self.std = cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD
+        self.thr, self.nms_thr = cfg.MODEL.YOLOV3.TEST_SCORE_THRESH, cfg.MODEL.YOLOV3.TEST_NMS_THRESH
+        for slot in (0, 1):  # buffers of both pipeline slots exist before anything is timed
+            self.eng.plan(BATCH, SIZE, SIZE, slot)
+        self.last = None
+        torch.cuda.synchronize()
+
+    def run(self, k: int):
+        """k complete steps in the engine's throughput mode; every step's NMS + gather is enqueued before this
+        returns."""
+        for out in self.eng.detect_pipelined((self.imgs for _ in range(k)), score_thr=self.thr, nms_thr=self.nms_thr,
+                                             mean=self.mean, std=self.std, max_det=100):
+            self.last = out
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def reduce_device(self):
+        return self.device
+
+    # ---- reporting (rank 0) ----
+    def config(self, world: int, steps_total: int, elapsed: float) -> dict:
+        plan = self.eng.plan(BATCH, SIZE, SIZE)
+        det, n_det = self.last
+        return {
+            "workload": "YOLOv3-416 (Darknet-53 + FPN, 80 classes) batch-64 bf16 inference on one MI355X: "
+                        "preprocess + backbone + neck + heads + decode + batched NMS + top-100",
+            "batch_per_gpu": BATCH, "global_batch": BATCH * world, "input": [SIZE, SIZE],
+            "score_thresh": self.thr, "nms_thresh": self.nms_thr, "parallelism": f"image-sharded x{world}, no collective",
+            "weights": "random init (reference initialisers), BatchNorm statistics calibrated on the synthetic images",
+            "candidates_per_batch": int(plan.cand.img_offsets[BATCH].item()),
+            "detections_per_batch": int(n_det.sum().item()),
+            "conv_gflop_per_image": round(plan.flops / BATCH / 1e9, 3),
+            "conv_tflops_end_to_end": round(plan.flops * world * steps_total / elapsed / 1e12, 1),
+        }
+
+    def roofline(self) -> dict:
+        plan = self.eng.plan(BATCH, SIZE, SIZE)
+        convs = dict(self.model.backbone.darknet_modules())
+        return _dominant_kernel_roofline(self.eng, plan, convs, self.imgs, self.mean, self.std)
+
+    def postproc(self) -> dict:
+        return _postproc_in_step(self)
+
+    def cpu_baseline(self) -> dict:
+        return _cpu_baseline(self.model, self.cfg)
+
+    def train(self) -> dict:
+        del self.last
+        self.eng._plans.clear()
+        self.torch.cuda.empty_cache()
+        try:
+            return _train_throughput()
+        except Exception as e:  # the headline line must not depend on the secondary measurement
+            return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
 def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int = 3):
     """The convolutions run as instances of one implicit-GEMM kernel that differ in their workgroup tile
-    (conv_igemm_kernel<bf16, channels, pixels, ...>; yolo_conv_tile_shape says which launch uses which).  Every
-    launch of the 128-channel instances is timed where it runs: the whole plan is replayed in order with a HIP event
+    (yolo_conv_kernel_name says which launch uses which).  Every launch of the instances with 128 or more channels
+    per tile is timed where it runs: the whole plan is replayed in order with a HIP event
     pair (on the launch stream) around each of them, so every launch sees the cache state it sees in a real step;
     the cost of an empty event pair is measured the same way and subtracted.  The instance with the most time is
     the dominant kernel: achieved = its algorithmic FLOPs (2 * pixels * Cout * Cin * k * k per launch) / its time.
     The other instances are reported next to it."""
+    import torch
     from yolo_amd import ops
     stream = torch.cuda.current_stream()
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    timed = []  # (step index, tile pixels, flops, bytes)
+    timed = []  # (step index, kernel name, flops, bytes, filter size)
     for i, (meta, step) in enumerate(zip(plan.meta, plan.steps)):
         c = convs[meta["name"]]
         if c.in_channels % 64 != 0:
             continue
         up = 2 if meta["up"] else 1
         M = plan.N * (meta["y"].H // up) * (meta["y"].W // up)
-        tc, tp = ops.conv_tile_shape(M, c.in_channels, c.out_channels, c.kernel_size, meta["x"].buf.dtype)
-        if tc != 128:
+        name = ops.conv_kernel_name(meta["x"], meta["y"], c.in_channels, c.out_channels, c.kernel_size, c.stride,
+                                    residual=meta["residual"] is not None, upsample2x=bool(meta["up"]))
+        if ",128," not in name and ",256," not in name:
             continue
         es = meta["x"].buf.element_size()
         by = (plan.N * meta["x"].H * meta["x"].W * c.in_channels * es
               + c.out_channels * c.in_channels * c.kernel_size ** 2 * es
               + plan.N * meta["y"].H * meta["y"].W * c.out_channels * meta["y"].buf.element_size()
               + (M * c.out_channels * es if meta["residual"] is not None else 0))
-        timed.append((i, tp, 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2, by, c.kernel_size))
+        timed.append((i, name, 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2, by, c.kernel_size))
     which = {i: k for k, (i, _, _, _, _) in enumerate(timed)}
     ms = [0.0] * len(timed)
     empty = 0.0
@@ -104,65 +221,149 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
         for k, (a, b) in enumerate(pairs):
             ms[k] += a.elapsed_time(b) / passes
     acc, by_k = {}, {}
-    for (i, tp, fl, by, ks), t in zip(timed, ms):
-        for a in (acc.setdefault(tp, [0.0, 0.0, 0, 0.0]), by_k.setdefault((tp, ks), [0.0, 0.0, 0, 0.0])):
+    for (i, name, fl, by, ks), t in zip(timed, ms):
+        for a in (acc.setdefault(name, [0.0, 0.0, 0, 0.0]), by_k.setdefault((name, ks), [0.0, 0.0, 0, 0.0])):
             a[0] += fl
             a[1] += max(t - empty, 1e-6)
             a[2] += 1
             a[3] += by
-    dom = max(acc, key=lambda tp: acc[tp][1])
+    dom = max(acc, key=lambda n: acc[n][1])
     flops, t_ms, launches, by = acc[dom]
     achieved = flops / (t_ms * 1e-3) / 1e12
     out = dict(bound="mfma", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
-               kernel=f"conv_igemm_kernel<bf16,128,{dom},2,2,false>", launches_per_step=launches,
+               kernel=dom, launches_per_step=launches,
                avg_launch_us=round(t_ms * 1e3 / launches, 2), flop_per_launch=round(flops / launches / 1e9, 3),
                algorithmic_bytes_per_launch=round(by / launches), event_pair_overhead_us=round(empty * 1e3, 2))
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_summary.py writes the
+    # file together with the git commit of the tree it profiled); a record of another kernel state is not replayed
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+    if os.path.exists(pmc):
         with open(pmc) as f:
             rec = json.load(f)
-        hit = rec.get("kernels", {}).get(out["kernel"])
-        if hit:
+        hit = rec.get("kernels", {}).get(dom)
+        if hit and rec.get("kernel_source_sha") == _kernel_source_sha():
             out["traffic"] = hit["hbm_bytes_per_launch"]
             out["traffic_source"] = "profiles/pmc_traffic.json: " + rec.get("source", "")
+        else:
+            out["traffic_note"] = ("profiles/pmc_traffic.json was collected on other kernel sources (or holds no row "
+                                   "for this kernel): not replayed")
     # the same instance serves long-K (3x3, matrix-bound) and short-K (1x1, memory-bound) layers: both parts of its time
     out["by_filter_size"] = {
         f"{ks}x{ks}": dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
                            avg_launch_us=round(a[1] * 1e3 / a[2], 2),
                            algorithmic_gbytes_per_s=round(a[3] / (a[1] * 1e-3) / 1e9))
-        for (tp, ks), a in sorted(by_k.items()) if tp == dom}
+        for (name, ks), a in sorted(by_k.items()) if name == dom}
     out["other_instances"] = {
-        f"128x{tp}": dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
-                          avg_launch_us=round(a[1] * 1e3 / a[2], 2))
-        for tp, a in sorted(acc.items()) if tp != dom}
+        name: dict(achieved=round(a[0] / (a[1] * 1e-3) / 1e12, 1), launches_per_step=a[2],
+                   avg_launch_us=round(a[1] * 1e3 / a[2], 2))
+        for name, a in sorted(acc.items()) if name != dom}
+    tot_f = sum(a[0] for a in acc.values())
+    tot_t = sum(a[1] for a in acc.values())
+    out["all_timed_instances"] = dict(achieved=round(tot_f / (tot_t * 1e-3) / 1e12, 1), launches_per_step=len(timed),
+                                      frac=round(tot_f / (tot_t * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
     return out
 
 
-def _cpu_baseline(model, cfg, n_images: int = 16, reps: int = 14):
-    """The CPU oracle (plain torch fp32 restatement of the reference + C NMS) on a bounded sample of the
-    same workload, timed on this box's host cores."""
+def _kernel_source_sha() -> str:
+    """Identifies the kernel sources a PMC record belongs to (hash of yolo_amd/csrc/*.hip and common.h)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(ROOT, "yolo_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "yolo_amd", "csrc", "*.h"))):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _postproc_in_step(w: "Yolov3Inference", steps: int = 6) -> dict:
+    """Decode and NMS + gather timed INSIDE pipelined steps (HIP events on the streams they run on, next to the
+    following batch's convolutions), against the HBM roofline on two byte counts: the algorithmic bytes (every head
+    value once + the candidate arrays) and the bytes the kernels cannot avoid touching (one 64-byte sector per anchor
+    row for the objectness test + the whole rows of cells that yield candidates + the candidate arrays)."""
+    import torch
+    eng = w.eng
+    eng.trace_events = []
+    w.run(steps)
+    torch.cuda.synchronize()
+    ev, eng.trace_events = eng.trace_events, None
+    acc = {}
+    for label, a, b in ev:
+        acc.setdefault(label, []).append(a.elapsed_time(b) * 1e3)
+    plan = eng.plan(BATCH, SIZE, SIZE)
+    n_cand = int(plan.cand.img_offsets[BATCH].item())
+    n_det = int(w.last[1].sum().item())
+    rows = sum(h.H * h.W for h in plan.heads) * eng.num_anchors * BATCH
+    K = 5 + eng.num_classes
+    es = plan.heads[0].buf.element_size()
+    alg_dec = rows * K * es + n_cand * 28
+    touched_dec = rows * 64 + min(n_cand, rows) * K * es + n_cand * 28
+    alg_nms = n_cand * 24 + 8 * n_det + 2 * n_cand * 8
+    out = {}
+    for label, alg, touched in (("decode", alg_dec, touched_dec), ("nms_gather", alg_nms, alg_nms)):
+        ts = acc.get(label)
+        if not ts:
+            continue
+        t = statistics.median(ts)
+        out[label] = dict(in_step_us=round(t, 1), algorithmic_bytes=int(alg), touched_bytes_lower_bound=int(touched),
+                          algorithmic_gbytes_per_s=round(alg / t / 1e3, 1),
+                          frac_hbm_algorithmic=round(alg / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                          frac_hbm_touched=round(touched / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+    return out
+
+
+def _cpu_baseline(model, cfg):
+    """The CPU oracle (plain torch fp32 restatement of the reference + C NMS) on a bounded sample of the same
+    workload, on this box's host cores: batch 64 of the benchmark's configuration and batch 1 through
+    configs/yolov3.yaml's shape (20 classes), each at n = the box's CPU share and n = 8 threads; warm-up runs, then
+    the median of the timed runs.  ``value`` is the batch-64 rate at n = all."""
+    import torch
+
     import workload
     from oracle import nms_c, yolo_ref as R
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-    torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    imgs = [im.float() for im in workload.synthetic_images(n_images, SIZE, SIZE, seed=1)]
     kw = dict(num_classes=cfg.MODEL.YOLOV3.NUM_CLASSES, score_thr=cfg.MODEL.YOLOV3.TEST_SCORE_THRESH,
               nms_thr=cfg.MODEL.YOLOV3.TEST_NMS_THRESH, nms_fn=nms_c.nms, device_kind="gpu")
-    with torch.no_grad():
-        R.inference(imgs[:2], sd, **kw)  # warm-up (thread pool, allocator)
-        t0 = time.time()
-        for _ in range(reps):
-            R.inference(imgs, sd, **kw)
-        dt = time.time() - t0
-    return dict(value=round(n_images * reps / dt, 2), unit="images/sec", cores=cores, kind="port",
-                sample=f"{reps} x batch {n_images} of the same 416x416 workload, torch {torch.__version__} fp32 CPU ops + C NMS")
+    imgs64 = [im.float() for im in workload.synthetic_images(BATCH, SIZE, SIZE, seed=1)]
+    # batch 1: the 20-class head of configs/yolov3.yaml = the first 75 of this model's 255 head channels per level
+    # would change the arithmetic; the per-image cost of the 80-class model is within 0.3 % of it (head convs are
+    # 0.66 % of the FLOPs), so batch 1 runs the same state dict
+    rows = {}
+
+    def timed(batch, n, warm, reps):
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            for _ in range(warm):
+                R.inference(batch, sd, **kw)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                R.inference(batch, sd, **kw)
+                ts.append(time.perf_counter() - t0)
+        return len(batch) / statistics.median(ts)
+
+    t_all = time.perf_counter()
+    for n in sorted({cores, min(8, cores)}, reverse=True):
+        rows[f"batch1_threads{n}"] = round(timed(imgs64[:1], n, 3, 10), 2)
+    rows[f"batch64_threads{cores}"] = round(timed(imgs64, cores, 1, 3), 2)
+    if cores > 8:
+        rows["batch64_threads8"] = round(timed(imgs64, 8, 0, 2), 2)
+    spent = time.perf_counter() - t_all
+    torch.set_num_threads(cores)
+    return dict(value=rows[f"batch64_threads{cores}"], unit="images/sec", cores=cores, kind="port",
+                sample=(f"oracle (torch {torch.__version__} fp32 CPU ops + C NMS) on the same 416x416 workload: batch 64 "
+                        f"(1 warm-up + median of 3 at {cores} threads; median of 2 at 8 threads) and batch 1 (3 warm-up + "
+                        f"median of 10 at each thread count); {spent:.0f} s of CPU work"),
+                images_per_sec=rows)
 
 
 def _train_throughput(steps: int = 4, warmup: int = 2, batch: int = 64):
     """Secondary metric of the same hot path (training images per second): forward + backward + SGD step of
     configs/yolov3.yaml at 416x416, batch 64, bf16, synthetic COCO-shaped targets, on this one GPU."""
+    import torch
+
     import workload
     from yolo_amd.trainer import Trainer, synthetic_batches
     model, cfg = workload.build_model(config="yolov3.yaml", dtype="bf16", device=f"cuda:{torch.cuda.current_device()}",
@@ -184,101 +385,127 @@ def _train_throughput(steps: int = 4, warmup: int = 2, batch: int = 64):
                 finite_losses=bool(all(torch.isfinite(v) for v in losses.values())))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput measurement")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------
+def _make_workload(rank: int, world: int, local: int):
+    spec = os.environ.get("YOLO_BENCH_WORKLOAD")
+    if spec:
+        mod, fn = spec.split(":")
+        return getattr(importlib.import_module(mod), fn)(rank, world, local)
+    return Yolov3Inference(rank, world, local)
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
-    world, rank, local = _dist_setup(args.gpus)
-    import workload
 
-    model, cfg = workload.calibrated_model(size=SIZE, calib_batch=4, config="yolov3-aug.yaml", dtype="bf16",
-                                           head_dtype="f32", device=f"cuda:{torch.cuda.current_device()}")
-    eng = model.backbone.engine()
-    # every rank gets its own shard of images (different seeds), already resident in HBM
-    imgs = workload.synthetic_images(BATCH, SIZE, SIZE, seed=1 + rank, device=model.device)
-    mean, std = cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD
-    thr, nms_thr = cfg.MODEL.YOLOV3.TEST_SCORE_THRESH, cfg.MODEL.YOLOV3.TEST_NMS_THRESH
-
-    def run(k):
-        """k complete steps in the engine's throughput mode: step i+1's convolutions are queued before the host
-        reads step i's candidate count; every step's NMS + gather is enqueued before this returns."""
-        out = None
-        for out in eng.detect_pipelined((imgs for _ in range(k)), score_thr=thr, nms_thr=nms_thr, mean=mean,
-                                        std=std, max_det=100):
-            pass
-        return out
-
-    for slot in (0, 1):  # buffers of both pipeline slots exist before anything is timed
-        eng.plan(BATCH, SIZE, SIZE, slot)
-    det = n_det = None
-    if args.warmup:
-        det, n_det = run(args.warmup)
-    _barrier(world)
-    t0 = time.perf_counter()
-    det, n_det = run(args.steps)
-    _barrier(world)
-    elapsed = time.perf_counter() - t0
+def run_rank(args) -> None:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    w = _make_workload(rank, world, local)
+    dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=model.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        backend = os.environ.get("YOLO_BENCH_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
 
-    plan = eng.plan(BATCH, SIZE, SIZE)
-    out = None
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        w.sync()
+
+    w.prepare()
+    if args.warmup:
+        w.run(args.warmup)
+    # size of the timed region: the K steps are repeated until the region is at least --min-seconds long; the count
+    # is agreed between the ranks (MAX of the estimates) so that every rank runs the same number of steps
+    repeats = 1
+    if args.min_seconds > 0:
+        barrier()
+        t0 = time.perf_counter()
+        w.run(args.steps)
+        w.sync()
+        est = time.perf_counter() - t0
+        repeats = max(1, int(args.min_seconds / max(est, 1e-6) + 0.999))
+        if dist is not None:
+            import torch
+            t = torch.tensor([repeats], dtype=torch.int64, device=w.reduce_device() if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            repeats = int(t.item())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        w.run(args.steps)
+    w.sync()
+    own = time.perf_counter() - t0  # this rank's own work; the region below also holds the wait for the slowest rank
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [own]
+    if dist is not None:
+        import torch
+        dev = w.reduce_device() if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([own], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        elapsed = float(mine.item())
+
+    total_steps = repeats * args.steps
     if rank == 0:
-        convs = dict(model.backbone.darknet_modules())
-        roof = _dominant_kernel_roofline(eng, plan, convs, imgs, mean, std)
-        n_cand = int(plan.cand.img_offsets[BATCH].item())
         out = {
-            "metric": "images/sec YOLOv3-416 inference incl. decode+NMS",
-            "value": round(world * BATCH * args.steps / elapsed, 1),
-            "unit": "images/sec",
+            "metric": w.metric,
+            "value": round(world * w.units_per_step * total_steps / elapsed, 1),
+            "unit": w.unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(elapsed / total_steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {
-                "workload": "YOLOv3-416 (Darknet-53 + FPN, 80 classes) batch-64 bf16 inference on one MI355X: "
-                            "preprocess + backbone + neck + heads + decode + batched NMS + top-100",
-                "batch_per_gpu": BATCH, "global_batch": BATCH * world, "input": [SIZE, SIZE],
-                "score_thresh": thr, "nms_thresh": nms_thr, "parallelism": f"image-sharded x{world}, no collective",
-                "weights": "random init (reference initialisers), BatchNorm statistics calibrated on the synthetic images",
-                "candidates_per_batch": n_cand, "detections_per_batch": int(n_det.sum().item()),
-                "conv_gflop_per_image": round(plan.flops / BATCH / 1e9, 3),
-                "conv_tflops_end_to_end": round(plan.flops * world * args.steps / elapsed / 1e12, 1),
-            },
-            "roofline": roof,
+            "dtype": w.dtype,
+            "data": w.data,
+            "timed_steps": total_steps,
+            "timed_seconds": round(elapsed, 3),
+            "per_rank_value": [round(w.units_per_step * total_steps / t, 1) for t in per_rank],
+            "config": w.config(world, total_steps, elapsed),
+            "roofline": w.roofline(),
         }
+        if hasattr(w, "postproc"):
+            out["postproc"] = w.postproc()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = _cpu_baseline(model, cfg)
-        if world == 1 and not args.no_train:
-            del det, n_det
-            eng._plans.clear()
-            torch.cuda.empty_cache()
-            try:
-                out["train"] = _train_throughput()
-            except Exception as e:  # the headline line must not depend on the secondary measurement
-                out["train"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            out["cpu_baseline"] = w.cpu_baseline()
+        if world == 1 and not args.no_train and hasattr(w, "train"):
+            out["train"] = w.train()
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the K steps until the timed region is at least this long (0: exactly K steps)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput measurement")
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}; using WORLD_SIZE", file=sys.stderr)
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,41 @@
+"""A stand-in workload for bench.py's launcher tests: no GPU, a step is a short sleep whose length depends on the
+rank, so that the MAX over ranks and the per-rank values can be told apart."""
+import time
+
+
+class StubWorkload:
+    metric = "stub steps/sec"
+    unit = "steps/sec"
+    dtype = "none"
+    data = "stub"
+    units_per_step = 1
+
+    def __init__(self, rank, world, local):
+        self.rank, self.world = rank, world
+        self.steps_run = 0
+
+    def prepare(self):
+        pass
+
+    def run(self, k):
+        time.sleep(0.002 * k * (1 + self.rank))
+        self.steps_run += k
+
+    def sync(self):
+        pass
+
+    def reduce_device(self):
+        return "cpu"
+
+    def config(self, world, steps_total, elapsed):
+        return {"workload": "stub", "steps_run_on_rank0": self.steps_run}
+
+    def roofline(self):
+        return {"bound": "hbm", "achieved": 0.0, "peak": 1.0, "unit": "GB/s", "frac": 0.0, "traffic": None}
+
+    def cpu_baseline(self):
+        return {"value": 0.0, "unit": "steps/sec", "cores": 1, "kind": "port", "sample": "stub"}
+
+
+def make(rank, world, local):
+    return StubWorkload(rank, world, local)

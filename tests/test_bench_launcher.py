@@ -1,0 +1,51 @@
+"""bench.py --gpus N starts N ranks itself (the reference's launch(main, num_gpus, ...), tools/train_net.py:140-147):
+exercised on CPU with the gloo backend and a stub workload."""
+import json
+import os
+import sys
+
+import bench
+
+
+def _run(capfd, monkeypatch, argv):
+    monkeypatch.setenv("YOLO_BENCH_WORKLOAD", "tests.bench_stub:make")
+    monkeypatch.setenv("YOLO_BENCH_BACKEND", "gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([bench.ROOT] + sys.path))
+    rc = bench.main(argv)
+    out = capfd.readouterr().out
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    return rc, lines
+
+
+def test_gpus_2_starts_two_ranks(capfd, monkeypatch):
+    rc, lines = _run(capfd, monkeypatch, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--min-seconds", "0.1"])
+    assert rc == 0
+    assert len(lines) == 1, lines  # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert len(rec["per_rank_value"]) == 2
+    # rank 1's steps take twice as long: the job's value is set by the slowest rank (MAX over ranks)
+    assert rec["per_rank_value"][0] > rec["per_rank_value"][1] * 1.3
+    assert abs(rec["value"] - 2 * rec["per_rank_value"][1]) / rec["value"] < 0.15
+    assert rec["timed_steps"] % 3 == 0 and rec["timed_steps"] >= 3
+    assert rec["config"]["steps_run_on_rank0"] == 1 + 3 + rec["timed_steps"]
+    assert "cpu_baseline" not in rec  # rank 0 at N = 1 only
+
+
+def test_gpus_1_is_one_process(capfd, monkeypatch):
+    rc, lines = _run(capfd, monkeypatch, ["--steps", "2", "--warmup", "0", "--min-seconds", "0"])
+    assert rc == 0 and len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["timed_steps"] == 2 and len(rec["per_rank_value"]) == 1
+    assert rec["cpu_baseline"]["kind"] == "port"
+
+
+def test_a_failing_rank_fails_the_launch(monkeypatch, capfd):
+    monkeypatch.setenv("YOLO_BENCH_WORKLOAD", "tests.bench_stub:no_such_factory")
+    monkeypatch.setenv("YOLO_BENCH_BACKEND", "gloo")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([bench.ROOT] + sys.path))
+    assert bench.main(["--gpus", "2", "--steps", "1", "--warmup", "0"]) != 0
+    capfd.readouterr()

@@ -8,10 +8,15 @@ Tolerances, as max|err| / max|ref| per tensor:
     fed the oracle's input for that layer, meets 5e-2 against the oracle's bf16 restatement (weights and
     layer outputs rounded to bfloat16, fp32 accumulation -- what a bf16 run of the reference computes);
   * bf16, whole chain: a randomly initialised, BatchNorm-calibrated Darknet-53 roughly doubles any
-    perturbation per stage (the fp32 GPU-vs-CPU difference grows 9e-7 -> 2e-5 the same way), so a single
-    flipped bf16 rounding early on is visible at the heads.  The chained bf16 plan is therefore bounded by
-    1e-1 against the bf16 restatement (measured 4e-2 .. 7e-2 at the heads) and 0.3 in relative L2 against
-    the fp32 oracle; that growth is a property of bf16 on this network, not of the kernels.
+    perturbation per stage (the fp32 GPU-vs-CPU difference grows 9e-7 -> 2e-5 the same way).  Rounding the
+    convolution OPERANDS to bf16 is enough for that: the oracle's own bf16 restatement is 3e-2 / 7e-2 / 1.2e-1
+    from its fp32 self at res3 / res4 / res5 and 1.0e-1 .. 1.45e-1 at the heads, and keeping the residual stream
+    in fp32 does not change these figures (tools/chain_error_variants.py) -- 5e-2 at the heads is not reachable
+    by ANY bf16 execution of this network, the reference's own included.  The chained bf16 plan is therefore
+    held to: (a) 5e-2 against the fp32 oracle where the chain is still short (res3); (b) at every tap an error
+    against the fp32 oracle no larger than 1.2 x the error of the oracle's bf16 restatement (+ 5e-3); (c) 1e-1
+    against the bf16 restatement (two bf16 runs that only differ in accumulation order; measured 4e-2 .. 7.5e-2
+    at the heads).  Detection-level agreement of the bf16 plan: tests/test_gpu_parity_configs.py.
 """
 import pytest
 import torch
@@ -33,8 +38,11 @@ def _check(got, ref, dtype, name, ref32=None):
     if dtype == torch.float32:
         assert _rel(got, ref) < 1e-3, name
     else:
+        own = _rel(ref, ref32)  # what bf16 costs the oracle itself at this tap
+        assert _rel(got, ref32) < 1.2 * own + 5e-3, (name, _rel(got, ref32), own)
         assert _rel(got, ref) < 1e-1, (name, _rel(got, ref))
-        assert _rel_l2(got, ref32) < 0.3, (name, _rel_l2(got, ref32))
+        if name == "res3":
+            assert _rel(got, ref32) < 5e-2, (name, _rel(got, ref32))
 
 
 @pytest.fixture(scope="module")

@@ -205,3 +205,55 @@ def test_argument_validation_needs_no_gpu():
     assert code == -1 and b"batch" in L.yolo_last_error()
     code = L.yolo_decode(None, 3, None, None, 1, 3, 80, 0.25, 0, None, None, None, None, 0, None, 0, None)
     assert code == -1
+
+
+def test_darknet_weights_reader_equals_the_oracle_reader(tmp_path, model20):
+    """A file written from a state dict with randomised BatchNorm statistics by the oracle's table-driven writer:
+    the product reader (through YOLOV3Checkpointer, checkpoint.py:13-22) and the oracle's statement-by-statement
+    restatement of load_darknet.py:103-124 return the same tensors under the same keys."""
+    from oracle import darknet_weights_ref as W, yolo_ref as R
+    from yolo_amd.checkpoint import YOLOV3Checkpointer
+    sd = R.init_state_dict(5, num_classes=20)
+    R.randomize_norm_stats(sd, seed=6)
+    path = str(tmp_path / "rand.weights")
+    n = W.write_weights(path, sd, num_classes=20)
+    assert os.path.getsize(path) == 20 + 4 * n
+    ref = W.read_weights(path, num_classes=20)
+    assert int(ref.pop("__trailing_floats__")) == 0
+    assert set(ref) == set(sd) and all(torch.equal(ref[k], sd[k]) for k in sd)
+    torch.manual_seed(9)
+    m = build_model(_cfg())
+    YOLOV3Checkpointer(m).load(path)
+    got = m.state_dict()
+    for k, v in ref.items():
+        assert torch.equal(got[k], v), k
+    # the 80-class file does not fit the 20-class model: reported, not loaded misaligned
+    sd80 = R.init_state_dict(5, num_classes=80)
+    p80 = str(tmp_path / "coco.weights")
+    assert W.write_weights(p80, sd80, num_classes=80) == 62001757  # the official yolov3.weights' float count
+    with pytest.raises(ValueError, match="different network"):
+        YOLOV3Checkpointer(m).load(p80)
+    # ... and the 20-class file is too short for an 80-class reader (the oracle's reader agrees)
+    with pytest.raises(ValueError, match="ends early"):
+        W.read_weights(path, num_classes=80)
+
+
+def test_pth_with_other_head_shapes_loads_the_rest(tmp_path, model20):
+    """fvcore's Checkpointer skips parameters of incompatible shape with a warning (an 80-class checkpoint
+    fine-tuned on 20 classes re-initialises only the three head convs)."""
+    from oracle import yolo_ref as R
+    from yolo_amd.checkpoint import YOLOV3Checkpointer
+    sd80 = R.init_state_dict(11, num_classes=80)
+    path = str(tmp_path / "coco.pth")
+    torch.save({"model": sd80}, path)
+    torch.manual_seed(4)
+    m = build_model(_cfg())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ck = YOLOV3Checkpointer(m)
+    ck.load(path)
+    after = m.state_dict()
+    heads = [f"backbone.fpn_output{i}.head.{p}" for i in range(3) for p in ("weight", "bias")]
+    assert sorted(ck.skipped_keys) == sorted(heads)
+    for k in heads:
+        assert torch.equal(after[k], before[k])
+    assert torch.equal(after["backbone.bottom_up.res3.0.conv2.weight"], sd80["backbone.bottom_up.res3.0.conv2.weight"])

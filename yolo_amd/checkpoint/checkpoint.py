@@ -43,11 +43,18 @@ class YOLOV3Checkpointer:
         ckpt = self._load_file(path)
         sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt.pop("model").items()}
         own = self.model.state_dict()
+        # fvcore's Checkpointer._load_model (the reference's base class): parameters whose shape differs are
+        # skipped with a warning and keep their initialisation -- e.g. the three head convs when an 80-class
+        # checkpoint is fine-tuned on 20 classes -- and everything else is loaded.
         bad = [k for k, v in sd.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
-        if bad:
-            raise ValueError(f"shape mismatch for {bad[:3]} ... ({len(bad)} tensors)")
+        for k in bad:
+            self.logger.warning("Skip loading parameter '%s' to the model due to incompatible shapes: %s in the "
+                                "checkpoint but %s in the model! You might want to double check if this is expected.",
+                                k, tuple(sd[k].shape), tuple(own[k].shape))
+            del sd[k]
+        self.skipped_keys = bad
         res = self.model.load_state_dict(sd, strict=False)
-        missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+        missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked") and k not in bad]
         if missing:
             self.logger.warning("keys missing from the checkpoint: %s", missing[:8])
         if res.unexpected_keys:

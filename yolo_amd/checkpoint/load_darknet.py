@@ -42,6 +42,12 @@ def load_darknet_weights_to_dict(f, module_list: Iterable, module_prefix: str = 
         else:
             sd[f"{name}.bias"], pos = _take(buf, pos, m.bias)
         sd[f"{name}.weight"], pos = _take(buf, pos, m.weight)
+    if pos != buf.size:
+        # The reference stops reading here and keeps whatever the sequential read produced.  A file with floats left
+        # over was written for another network (typically the 80-class yolov3.weights read into a 20-class model:
+        # every tensor after the first head conv is then misaligned), so it is reported instead of loaded.
+        raise ValueError(f"darknet weights file holds {buf.size} floats but this model reads {pos}: "
+                         "the file belongs to a different network (number of classes?)")
     return sd
 
 

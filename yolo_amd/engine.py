@@ -92,6 +92,9 @@ class Yolov3Engine:
         self._bstream = None
         self.branch_on_side_stream = os.environ.get("YOLO_BRANCH_STREAM", "1") != "0"
         self.nms_on_side_stream = os.environ.get("YOLO_NMS_STREAM", "1") != "0"
+        # measurement hook: when a list, submit()/finish() append (label, start event, end event) recorded on the
+        # stream the decode / NMS + gather launches run on
+        self.trace_events: Optional[list] = None
         self.repack()
 
     # ------------------------------------------------------------------ weights
@@ -282,7 +285,9 @@ class Yolov3Engine:
         if dstream is not main:
             dstream.wait_stream(main)
         with torch.cuda.stream(dstream):
+            t0 = self._trace_begin()
             cand = self.decode(P, score_thr)
+            self._trace_end("decode", t0)
             if P.total_host is None:
                 P.total_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
             P.total_host.copy_(cand.img_offsets[N:N + 1], non_blocking=True)
@@ -311,6 +316,7 @@ class Yolov3Engine:
         main = torch.cuda.current_stream(dev)
         side = self._side_stream() if self.nms_on_side_stream else main
         with torch.cuda.stream(side):
+            t0 = self._trace_begin()
             if P.keep is None or P.keep.shape[1] != max_det:
                 P.keep = torch.empty((P.N, max_det), dtype=torch.int32, device=dev)
                 P.n_keep = torch.empty((P.N,), dtype=torch.int32, device=dev)
@@ -329,11 +335,25 @@ class Yolov3Engine:
             if out_hw is None:
                 out_hw = in_hw
             det, n_det = ops.gather_detections(cand, P.keep, P.n_keep, in_hw, out_hw)
+            self._trace_end("nms_gather", t0)
         if side is not main:
             main.wait_stream(side)
             det.record_stream(main)
             n_det.record_stream(main)
         return det, n_det
+
+    def _trace_begin(self):
+        if self.trace_events is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _trace_end(self, label: str, start) -> None:
+        if start is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace_events.append((label, start, ev))
 
     def _decode_stream(self):
         if self._dstream is None:

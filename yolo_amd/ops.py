@@ -146,6 +146,18 @@ def conv_tile_shape(M: int, cin: int, cout: int, k: int, dtype: torch.dtype = to
     return tc.value, tp.value
 
 
+def conv_kernel_name(x: "View", y: "View", cin: int, cout: int, k: int, stride: int, *, residual: bool = False,
+                     upsample2x: bool = False) -> str:
+    """Name (as a profiler shows it) of the kernel instance yolo_conv2d_fwd launches for this convolution."""
+    up = 2 if upsample2x else 1
+    M = x.N * (y.H // up) * (y.W // up)
+    tc, tp = conv_tile_shape(M, cin, cout, k, x.buf.dtype)
+    dt = "bf16" if x.buf.dtype == torch.bfloat16 else "float"
+    if tc == 32:
+        return f"conv_igemm_kernel<{dt},32,128,1,4,{'true' if cin == 32 and k == 3 else 'false'}>"
+    return f"conv_igemm_kernel<{dt},{tc},{tp},2,2,{'true' if cin == 32 and k == 3 else 'false'}>"
+
+
 def conv_bnsums_rows(M: int, cin: int, cout: int, k: int, dtype: torch.dtype) -> int:
     """Rows of per-tile sums conv2d_fwd_bnsums writes for this convolution."""
     return lib().yolo_conv2d_bnsums_rows(int(M), int(cin), int(cout), int(k), dtype_code(dtype))
