@@ -41,10 +41,11 @@ def build_model(config: str = "yolov3-aug.yaml", device: str = "cuda", dtype: st
     return model, cfg
 
 
-def calibrated_model(size: int = 416, calib_batch: int = 4, obj_bias: float = -4.5, **kw):
+def calibrated_model(size: int = 416, calib_batch: int = 4, obj_bias: float = -4.5, residual_gain=None, **kw):
     """build_model + BatchNorm statistics / head scale calibrated on ``calib_batch`` synthetic images."""
     from yolo_amd.utils.calibrate import calibrate_norm_stats
     model, cfg = build_model(**kw)
     imgs = synthetic_images(calib_batch, size, size, seed=12345, device=model.device).float()
-    calibrate_norm_stats(model.backbone, imgs, mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD, obj_bias=obj_bias)
+    calibrate_norm_stats(model.backbone, imgs, mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD, obj_bias=obj_bias,
+                         residual_gain=residual_gain)
     return model, cfg

@@ -19,8 +19,15 @@ from .. import ops
 
 @torch.no_grad()
 def calibrate_norm_stats(backbone, images: torch.Tensor, mean=(0.0, 0.0, 0.0), std=(255.0, 255.0, 255.0),
-                         head_logit_std: Optional[float] = 1.0, obj_bias: Optional[float] = -4.5) -> None:
-    """backbone: DarkNetFPN on the GPU; images [N,3,H,W] (0..255), H and W multiples of 32.  In place."""
+                         head_logit_std: Optional[float] = 1.0, obj_bias: Optional[float] = -4.5,
+                         residual_gain: Optional[float] = None) -> None:
+    """backbone: DarkNetFPN on the GPU; images [N,3,H,W] (0..255), H and W multiples of 32.  In place.
+
+    ``residual_gain``: BatchNorm weight given to the last conv of every residual block (None keeps the
+    constructor's 1).  With gain 1 every block doubles the variance of the stream it adds to and the network
+    amplifies relative perturbations about twofold per stage; a small gain (the "zero-gamma" initialisation trained
+    residual networks start from) gives a well-conditioned network, which is what a test needs when it wants to see
+    the arithmetic error of the kernels rather than the network's own sensitivity."""
     from ..engine import Yolov3Engine
     dev = next(backbone.parameters()).device
     images = images.to(dev)
@@ -54,6 +61,8 @@ def calibrate_norm_stats(backbone, images: torch.Tensor, mean=(0.0, 0.0, 0.0), s
             ops.conv2d_fwd(x, wr, br, tmp, cin=conv.in_channels, cout=conv.out_channels, k=conv.kernel_size,
                            stride=conv.stride, slope=1.0)
             set_stats(conv, tmp.interior()[..., :conv.out_channels])
+            if residual_gain is not None and meta["residual"] is not None:
+                conv.norm.weight.fill_(residual_gain)
         elif head_logit_std is not None:
             wr, br = ops.pack_conv(conv.weight.detach().float(), torch.zeros(conv.out_channels), torch.float32, dev)
             ops.conv2d_fwd(x, wr, br, tmp, cin=conv.in_channels, cout=conv.out_channels, k=conv.kernel_size,
