@@ -265,3 +265,27 @@ def test_side_stream_postprocessing_equals_single_stream(cuda, calibrated):
         for i in range(d0.shape[0]):
             k = int(n0[i])
             assert torch.equal(d0[i, :k], d1[i, :k])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_model_on_a_gpu_that_is_not_the_current_device():
+    """A model placed on cuda:1 while the current device stays 0 (MODEL.DEVICE: 'cuda:1' without set_device) runs
+    every launch on cuda:1's streams and returns what the same model returns on cuda:0."""
+    assert torch.cuda.current_device() == 0
+    m0, cfg = workload.calibrated_model(size=128, calib_batch=2, config="yolov3-aug.yaml", dtype="bf16", device="cuda:0")
+    m1, _ = workload.build_model(config="yolov3-aug.yaml", dtype="bf16", device="cuda:1")
+    m1.load_state_dict(m0.state_dict())
+    m0.test_score_thresh = m1.test_score_thresh = 0.02
+    imgs = workload.synthetic_images(2, 128, 128, seed=3)
+    r0 = m0([dict(image=i) for i in imgs])
+    r1 = m1([dict(image=i) for i in imgs])
+    assert torch.cuda.current_device() == 0
+    for a, b in zip(r0, r1):
+        assert b["instances"].pred_boxes.tensor.device.index == 1
+        assert torch.equal(a["instances"].pred_boxes.tensor.cpu(), b["instances"].pred_boxes.tensor.cpu())
+        assert torch.equal(a["instances"].scores.cpu(), b["instances"].scores.cpu())
+    # an operator handed another GPU's tensor without the guard refuses instead of racing
+    from yolo_amd import ops
+    v = ops.alloc_view(1, 8, 8, 64, 1, torch.bfloat16, torch.device("cuda:1"))
+    with pytest.raises(RuntimeError, match="current device"):
+        ops.upsample2x(v, v)

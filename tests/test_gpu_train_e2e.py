@@ -486,3 +486,55 @@ def test_side_stream_weight_gradients_equal_the_single_stream_ones(cuda):
             continue
         for n in grads:
             assert torch.equal(got[n], grads[n]), (side, n)
+
+
+def test_multi_scale_training_80_classes(cuda):
+    """configs/yolov3-aug.yaml (80 classes) with the side of the batch drawn per step from the multi-scale list
+    (the reference's INPUT.MIN_SIZE_TRAIN, configs/yolov3.yaml:36; yolov3-aug.yaml:35-38 trains the same network):
+    six steps over {320, 416, 512, 608} with one plan per side, finite losses throughout, the resident plans bounded by
+    the cache's limits (least recently used plan evicted), and the first step at the smallest side equal to the
+    oracle's training forward on the same state dict (fp32 plan)."""
+    from oracle import yolo_train_ref as T
+    from yolo_amd.structures import Boxes, Instances
+    model, cfg = workload.build_model(config="yolov3-aug.yaml", dtype="f32")
+    C = cfg.MODEL.YOLOV3.NUM_CLASSES
+    assert C == 80
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-5, momentum=0.9)
+    eng = model.backbone.train_engine()
+    N = 2
+    sides = [320, 608, 416, 512, 320, 608]
+    one_plan = None
+    for step, S in enumerate(sides):
+        imgs = workload.synthetic_images(N, S, S, seed=50 + step)
+        gb, gc = T.synthetic_targets(N, S, C, seed=60 + step, max_boxes=8)
+        inputs = [dict(image=im, instances=Instances((S, S), gt_boxes=Boxes(b), gt_classes=c))
+                  for im, b, c in zip(imgs, gb, gc)]
+        if step == 0:
+            with torch.no_grad():
+                want = T.forward_training(imgs.float() / 255.0, sd, gb, gc, C, freeze_at=2)
+        opt.zero_grad(set_to_none=False)
+        losses = model(inputs)
+        total = sum(losses.values())
+        total.backward()
+        assert all(bool(torch.isfinite(v)) for v in losses.values()), (step, S, losses)
+        if step == 0:
+            for k in want:
+                assert abs(float(losses[k]) - float(want[k])) / abs(float(want[k])) < 1e-3, (k, float(losses[k]), float(want[k]))
+            assert eng._plans.nbytes > 0
+            eng._plans.max_plans = 2  # from here on at most two sides stay resident
+        opt.step()
+        assert len(eng._plans) <= 2
+    torch.cuda.synchronize()
+    assert eng._plans.evictions >= 3 and (2, 608, 608) in eng._plans
+    # the byte budget evicts as well: with a budget below one plan only the newest plan stays
+    eng._plans.budget_bytes = 1
+    # an evicted side is rebuilt on demand and still trains
+    S = 416
+    imgs = workload.synthetic_images(N, S, S, seed=99)
+    gb, gc = T.synthetic_targets(N, S, C, seed=98, max_boxes=8)
+    losses = model([dict(image=im, instances=Instances((S, S), gt_boxes=Boxes(b), gt_classes=c)) for im, b, c in zip(imgs, gb, gc)])
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+    assert eng._plans.keys() == [(2, 416, 416)]
+    model.eval()

@@ -23,6 +23,7 @@ import torch
 
 from . import ops
 from .ops import View
+from .utils.plan_cache import PlanCache
 
 
 @dataclass
@@ -85,7 +86,7 @@ class Yolov3Engine:
         if self.device.type != "cuda":
             raise RuntimeError("Yolov3Engine needs the model on an MI355X (cuda device); there is no CPU path")
         self._packed: Dict[str, PackedConv] = {}
-        self._plans: Dict[Tuple[int, int, int, int], Plan] = {}
+        self._plans = PlanCache(self.device)  # (N, H, W, slot) -> Plan, least recently used first out
         self._in_hw: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._side = None
         self._dstream = None
@@ -98,6 +99,7 @@ class Yolov3Engine:
         self.repack()
 
     # ------------------------------------------------------------------ weights
+    @ops.on_own_device
     def repack(self) -> None:
         """(Re)build folded + packed weights from the module's current parameters."""
         self._packed.clear()
@@ -111,12 +113,10 @@ class Yolov3Engine:
         self._plans.clear()
 
     # ------------------------------------------------------------------ plan
+    @ops.on_own_device
     def plan(self, N: int, H: int, W: int, slot: int = 0) -> Plan:
         """Cached plan for a batch shape; plans with different ``slot`` own independent buffers."""
-        key = (N, H, W, slot)
-        if key not in self._plans:
-            self._plans[key] = self._build_plan(N, H, W)
-        return self._plans[key]
+        return self._plans.get((N, H, W, slot), lambda: self._build_plan(N, H, W))
 
     def _build_plan(self, N: int, H: int, W: int) -> Plan:
         assert H % 32 == 0 and W % 32 == 0, "input must be padded to the backbone's size_divisibility (32)"
@@ -211,6 +211,7 @@ class Yolov3Engine:
         return P
 
     # ------------------------------------------------------------------ execution
+    @ops.on_own_device
     def run_backbone(self, images: torch.Tensor, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0),
                      padded_hw: Optional[Tuple[int, int]] = None, plan: Optional[Plan] = None) -> Plan:
         """images: [N,3,Hs,Ws] float32 or uint8 on the GPU.  Pixel normalisation with (mean, std) and
@@ -241,6 +242,7 @@ class Yolov3Engine:
         main.wait_stream(side)
         return P
 
+    @ops.on_own_device
     def run_backbone_prefix(self, images: torch.Tensor, mean, std, P: Plan) -> None:
         """The launches that precede ``P.steps``: stem (fused with the first down-sampling conv in bf16) and the
         fused residual blocks of the first stage."""
@@ -254,6 +256,7 @@ class Yolov3Engine:
         for step in P.pre_steps:
             step()
 
+    @ops.on_own_device
     def decode(self, P: Plan, score_thr: float, cap: Optional[int] = None) -> ops.Candidates:
         if cap is None:
             cap = P.N * 4096
@@ -267,6 +270,7 @@ class Yolov3Engine:
         return ops.decode(P.heads, self.strides, self.anchors_wh, self.num_classes, score_thr,
                           P.cand.scores.numel(), out=P.cand, workspace=P.decode_ws)
 
+    @ops.on_own_device
     def submit(self, images: torch.Tensor, *, score_thr: float, mean, std, padded_hw=None, slot: int = 0) -> "InFlight":
         """First half of detect(): enqueue backbone + neck + heads + decode for a batch and start the
         asynchronous read-back of the candidate count.  Nothing here waits for the GPU.  ``slot`` selects one of
@@ -295,6 +299,7 @@ class Yolov3Engine:
             ev.record()
         return InFlight(P, cand, ev, score_thr, (N, Hs, Ws))
 
+    @ops.on_own_device
     def finish(self, h: "InFlight", *, nms_thr: float, max_det: int = 100, nms_mode: int = ops.NMS_AUTO,
                auto_limit: int = 20000, in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
         """Second half of detect(): wait for the candidate count of a submitted batch (the one host read-back

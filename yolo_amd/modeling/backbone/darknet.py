@@ -52,6 +52,9 @@ class BasicStem(CNNBlockBase):
     def forward(self, x: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("yolo_amd runs on MI355X only: input is on the CPU and there is no CPU fallback")
+        if x.device.index != torch.cuda.current_device():  # launch on the GPU that holds the input
+            with torch.cuda.device(x.device):
+                return self.forward(x, dtype)
         N, _, H, W = x.shape
         w, b = self.conv.packed(dtype)
         y = ops.alloc_view(N, H, W, self.out_channels, 0, dtype, x.device)

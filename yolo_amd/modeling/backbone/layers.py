@@ -91,6 +91,9 @@ class Conv2d(nn.Module):
                                       "path yet; call .eval()")
         if not x.is_cuda:
             raise RuntimeError("yolo_amd runs on MI355X only: input is on the CPU and there is no CPU fallback")
+        if x.device.index != torch.cuda.current_device():  # launch on the GPU that holds the input
+            with torch.cuda.device(x.device):
+                return self.forward(x, slope, residual, dtype)
         dtype = dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
         N, _, H, W = x.shape
         k, s = self.kernel_size, self.stride

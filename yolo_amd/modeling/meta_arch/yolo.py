@@ -144,6 +144,7 @@ class YOLOV3(nn.Module):
                 batch[n, :, :i.shape[-2], :i.shape[-1]] = i.to(device=dev, dtype=torch.float32)
         return batch, sizes
 
+    @ops.on_own_device
     def forward(self, batched_inputs: List[Dict]):
         if self.training:
             return self.training_step(batched_inputs)

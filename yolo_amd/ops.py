@@ -36,9 +36,30 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _require_cuda(t: torch.Tensor, what: str):
+    """Every operator launches on the current stream of the CURRENT device.  A tensor that lives on another GPU
+    would be computed on by the wrong device's stream (a silent race or a fault), so it is refused here; the engines
+    and the model enter ``torch.cuda.device(their device)`` themselves (``on_own_device``)."""
     if not t.is_cuda:
         raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path needs a GPU tensor "
                            "(there is no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{what}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"call under `with torch.cuda.device({t.device.index})`")
+
+
+def on_own_device(method):
+    """Decorator for methods of objects with a ``.device``: run under that GPU's device guard, so that
+    ``torch.cuda.current_stream()`` and every launch refer to the GPU that holds the object's memory."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        dev = self.device
+        if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return method(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return method(self, *args, **kwargs)
+    return wrapper
 
 
 @dataclass

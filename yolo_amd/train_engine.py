@@ -35,6 +35,7 @@ import torch
 
 from . import ops
 from .ops import View
+from .utils.plan_cache import PlanCache
 
 LEAKY = 0.1
 BN_EPS = 1e-5
@@ -109,7 +110,7 @@ class TrainEngine:
                     p = f"bottom_up.res{si}.{b}"
                     names += ([p + ".downsample"] if b == 0 else []) + [p + ".conv1", p + ".conv2"]
         self.frozen.update(names)
-        self._plans: Dict[Tuple[int, int, int], TPlan] = {}
+        self._plans = PlanCache(self.device)  # (N, H, W) -> TPlan; multi-scale training keeps one plan per scale
         self._wcache: Dict[str, tuple] = {}
         self._wbufs: Dict[str, tuple] = {}
         self._zero_bias: Dict[int, torch.Tensor] = {}
@@ -229,11 +230,9 @@ class TrainEngine:
         return pw, pb
 
     # ------------------------------------------------------------------ plan
+    @ops.on_own_device
     def plan(self, N: int, H: int, W: int) -> TPlan:
-        key = (N, H, W)
-        if key not in self._plans:
-            self._plans[key] = self._build(N, H, W)
-        return self._plans[key]
+        return self._plans.get((N, H, W), lambda: self._build(N, H, W))
 
     def _build(self, N: int, H: int, W: int) -> TPlan:
         assert H % 32 == 0 and W % 32 == 0
@@ -397,6 +396,7 @@ class TrainEngine:
         return True  # produced by the fused frozen prefix
 
     # ------------------------------------------------------------------ forward
+    @ops.on_own_device
     def forward(self, images: torch.Tensor, mean, std, *, update_running_stats: bool = True) -> List[View]:
         """images [N,3,Hs,Ws] uint8/float32 (0..255) on the GPU; returns the head views p3, p4, p5 (f32 NHWC)."""
         N, _, Hs, Ws = images.shape
@@ -440,6 +440,7 @@ class TrainEngine:
         return P.heads
 
     # ------------------------------------------------------------------ backward
+    @ops.on_own_device
     def backward(self, P: TPlan, dheads: Optional[Sequence[torch.Tensor]]) -> None:
         """dheads: gradients of the loss w.r.t. the head tensors p3, p4, p5 as [N, A*(5+C), G, G] (any strides), or
         None when P.dheads already hold them (written by ops.train_loss_bwd).  Fills L.dW / dgamma / dbeta / dbias

@@ -30,6 +30,9 @@ def calibrate_norm_stats(backbone, images: torch.Tensor, mean=(0.0, 0.0, 0.0), s
     the arithmetic error of the kernels rather than the network's own sensitivity."""
     from ..engine import Yolov3Engine
     dev = next(backbone.parameters()).device
+    if dev.type == "cuda" and dev.index != torch.cuda.current_device():  # launch on the GPU that holds the model
+        with torch.cuda.device(dev):
+            return calibrate_norm_stats(backbone, images, mean, std, head_logit_std, obj_bias, residual_gain)
     images = images.to(dev)
     eng = Yolov3Engine(backbone, num_classes=backbone._num_classes, anchors_wh=backbone._anchors_wh,
                        dtype=torch.float32, head_dtype=torch.float32, blocks=backbone.bottom_up.blocks_per_stage)
