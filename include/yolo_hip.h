@@ -84,18 +84,6 @@ int yolo_conv_cout_pad(int Cout);
 int yolo_conv_tile_shape(int M, int Cin, int Cout, int k, int dtype, int* tile_channels, int* tile_pixels);
 
 /*
- * Alternative kernel for the 3x3 / stride-1 / bf16 case of yolo_conv2d_fwd (same reference call sites,
- * same epilogue minus the upsample): the input patch of a 128-pixel tile stays in LDS and the 9 taps are
- * row offsets into it, so a third of the bytes cross the L2 -> LDS path.  Opt-in: on MI355X it is
- * currently 5-10 % slower than yolo_conv2d_fwd.
- *   w_packed  [Cout_pad][Cin/32][kh][kw][32] bf16, each row zero-padded to an even number of 32-wide steps
- *   Cin == 32 or Cin % 64 == 0; x.halo >= 1; y has x's spatial size
- */
-int yolo_conv3x3_patch_fwd(const yolo_view* x, const void* w_packed, const float* bias,
-                           const yolo_view* residual, const yolo_view* y,
-                           int N, int Cin, int Cout, float leaky_slope, void* stream);
-
-/*
  * First layer: pixel normalisation + zero padding + 3x3/s1 stem conv + bias + LeakyReLU.
  * Replaces DenseDetector.preprocess_image (driven by configs/yolov3.yaml:5-6 and fpn.py:161-163)
  * and BasicStem.forward (darknet.py:57-60).

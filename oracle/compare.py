@@ -29,3 +29,19 @@ def matched_fraction(ref: torch.Tensor, got: torch.Tensor, min_score: float, iou
 
 def rows_of(boxes: torch.Tensor, scores: torch.Tensor, classes: torch.Tensor) -> torch.Tensor:
     return torch.cat([boxes.float(), scores.float()[:, None], classes.float()[:, None]], 1)
+
+
+def resize_shortest_edge(image, short: int, max_size: int):
+    """What the reference's Predictor does to an HWC uint8 image on the host (tools/inference.py:29-31,41:
+    detectron2 ``ResizeShortestEdge([short, short], max_size)``): scale so that the shorter side equals ``short``,
+    cap the longer side at ``max_size``, round to integers, Pillow bilinear.  Pinned: it IS Pillow."""
+    import numpy as np
+    from PIL import Image
+    h, w = image.shape[:2]
+    scale = short * 1.0 / min(h, w)
+    newh, neww = (short, scale * w) if h < w else (scale * h, short)
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    neww, newh = int(neww + 0.5), int(newh + 0.5)
+    return np.asarray(Image.fromarray(np.ascontiguousarray(image)).resize((neww, newh), Image.BILINEAR))

@@ -352,6 +352,7 @@ def test_predictor_preprocess_on_device_equals_the_host_path(cuda):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import inference as cli
+    from oracle.compare import resize_shortest_edge
     from yolo_amd.config import get_cfg
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(root, "configs", "yolov3.yaml"))
@@ -360,7 +361,7 @@ def test_predictor_preprocess_on_device_equals_the_host_path(cuda):
     for h, w in [(375, 500), (480, 640), (640, 427), (416, 416), (300, 900)]:
         bgr = _img(h, w, h + w)
         got = pred.preprocess(bgr)
-        want = cli.resize_shortest_edge(np.ascontiguousarray(bgr[:, :, ::-1]), 416, 608).transpose(2, 0, 1)
+        want = resize_shortest_edge(np.ascontiguousarray(bgr[:, :, ::-1]), 416, 608).transpose(2, 0, 1)
         assert got.dtype == torch.uint8 and got.is_cuda and tuple(got.shape) == want.shape
         assert np.array_equal(got.cpu().numpy(), want)
     out = pred(_img(375, 500, 1))["instances"]

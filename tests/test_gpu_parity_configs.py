@@ -47,16 +47,9 @@ def _ref_rows(r):
 def _oracle_preprocess(bgr: np.ndarray, short: int, max_size: int, fmt: str) -> torch.Tensor:
     """What Predictor.__call__ does on the host in the reference (tools/inference.py:36-43): optional BGR -> RGB,
     detectron2 ResizeShortestEdge (Pillow bilinear), HWC -> CHW float32."""
-    from PIL import Image
+    from oracle.compare import resize_shortest_edge
     img = bgr[:, :, ::-1] if fmt == "RGB" else bgr
-    h, w = img.shape[:2]
-    scale = short * 1.0 / min(h, w)
-    newh, neww = (short, scale * w) if h < w else (scale * h, short)
-    if max(newh, neww) > max_size:
-        s = max_size * 1.0 / max(newh, neww)
-        newh, neww = newh * s, neww * s
-    neww, newh = int(neww + 0.5), int(newh + 0.5)
-    out = np.asarray(Image.fromarray(np.ascontiguousarray(img)).resize((neww, newh), Image.BILINEAR))
+    out = resize_shortest_edge(img, short, max_size)
     return torch.as_tensor(out.astype("float32").transpose(2, 0, 1))
 
 

@@ -257,3 +257,18 @@ def test_pth_with_other_head_shapes_loads_the_rest(tmp_path, model20):
     for k in heads:
         assert torch.equal(after[k], before[k])
     assert torch.equal(after["backbone.bottom_up.res3.0.conv2.weight"], sd80["backbone.bottom_up.res3.0.conv2.weight"])
+
+
+def test_anchor_offset_other_than_half_is_refused():
+    cfg = _cfg(opts=["MODEL.ANCHOR_GENERATOR.OFFSET", 0.25])
+    with pytest.raises(NotImplementedError, match="OFFSET"):
+        build_model(cfg)
+
+
+def test_unported_augmentations_say_so():
+    with pytest.raises(NotImplementedError, match="not ported"):
+        from yolo_amd.data import RandomMedianBlur  # noqa: F401
+    with pytest.raises(NotImplementedError, match="not ported"):
+        from yolo_amd.data.transforms import PixelDropoutTransform  # noqa: F401
+    with pytest.raises(ImportError):
+        from yolo_amd.data import NoSuchThing  # noqa: F401

@@ -1,5 +1,5 @@
 """Single-layer convolution micro-benchmark (for rocprofv3 counter passes and A/B timing).
-usage: conv_bench.py CIN COUT K STRIDE H [N=64] [REPS=20] [RES=0] [PATCH=0]"""
+usage: conv_bench.py CIN COUT K STRIDE H [N=64] [REPS=20] [RES=0]"""
 import sys
 
 import torch
@@ -19,15 +19,11 @@ def main():
     x = ops.alloc_view(N, H, H, cin, 1, torch.bfloat16, dev)
     x.interior().copy_(torch.randn(N, H, H, cin, generator=g).to(dev))
     w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
-    patch = len(a) > 8 and a[8] == 1
-    wp, bp = ops.pack_conv(w, torch.zeros(cout), torch.bfloat16, dev, patch_layout=patch)
+    wp, bp = ops.pack_conv(w, torch.zeros(cout), torch.bfloat16, dev)
     Ho = (H + 2 * (k // 2) - k) // s + 1
     y = ops.alloc_view(N, Ho, Ho, cout, 1, torch.bfloat16, dev)
     r = ops.alloc_view(N, Ho, Ho, cout, 1, torch.bfloat16, dev) if res else None
-    if patch:
-        run = lambda: ops.conv3x3_patch_fwd(x, wp, bp, y, cin=cin, cout=cout, residual=r)
-    else:
-        run = lambda: ops.conv2d_fwd(x, wp, bp, y, cin=cin, cout=cout, k=k, stride=s, residual=r)
+    run = lambda: ops.conv2d_fwd(x, wp, bp, y, cin=cin, cout=cout, k=k, stride=s, residual=r)
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

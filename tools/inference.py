@@ -27,20 +27,6 @@ from yolo_amd.config import get_cfg  # noqa: E402
 from yolo_amd.modeling import build_model  # noqa: E402
 
 
-def resize_shortest_edge(image: np.ndarray, short: int, max_size: int) -> np.ndarray:
-    """detectron2 ResizeShortestEdge([short, short], max_size) on an HWC uint8 image: scale so that the
-    shorter side equals ``short``, cap the longer side at ``max_size``, round to integers, bilinear."""
-    from PIL import Image
-    h, w = image.shape[:2]
-    scale = short * 1.0 / min(h, w)
-    newh, neww = (short, scale * w) if h < w else (scale * h, short)
-    if max(newh, neww) > max_size:
-        s = max_size * 1.0 / max(newh, neww)
-        newh, neww = newh * s, neww * s
-    neww, newh = int(neww + 0.5), int(newh + 0.5)
-    return np.asarray(Image.fromarray(image).resize((neww, newh), Image.BILINEAR))
-
-
 class Predictor:
     """model.eval() + checkpoint load + shortest-edge resize + BGR->RGB flip + CHW float tensor, one image
     per call (reference tools/inference.py:23-45)."""

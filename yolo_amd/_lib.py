@@ -58,7 +58,6 @@ SIGNATURES = {
     "yolo_abi_version": (c_int, []),
     "yolo_conv_cout_pad": (c_int, [c_int]),
     "yolo_conv_tile_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, _IP, _IP]),
-    "yolo_conv3x3_patch_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_float, c_void_p]),
     "yolo_conv2d_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_int, c_int, c_void_p]),
     "yolo_stem_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p, c_void_p, _VP,

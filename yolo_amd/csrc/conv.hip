@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -600,11 +601,13 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     constexpr int LDS = LDS0;
 #endif
     auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    // the kernel's dynamic-LDS limit is raised once per instance (and process), whichever thread launches first
+    static std::once_flag attr_once;
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_status = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    });
+    YOLO_CHECK_HIP(attr_status);
     const int nblocks = p.n_ctiles * p.n_ptiles;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), LDS, stream, p);
     YOLO_CHECK_HIP(hipGetLastError());
@@ -635,8 +638,10 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 // set-up three times as often (measured ~1.5 x the cost per pixel), but fills the chip on layers with few pixels;
 // it is only considered for 1x1 layers with K <= 512, where nothing else does.
 static int pick_tp(int M, int n_ctiles, int nsteps) {
-    static const int force = getenv("YOLO_TP") ? atoi(getenv("YOLO_TP")) : 0;
+#ifdef YOLO_CONV_TRACE
+    static const int force = getenv("YOLO_TP") ? atoi(getenv("YOLO_TP")) : 0;  // measurement builds: pin the tile
     if (force == 64 || force == 96 || force == 128 || force == 192) return force;
+#endif
     auto cost = [&](int tp, long long per_pixel, long long slots) {
         const long long tiles = (long long)((M + tp - 1) / tp) * n_ctiles;
         // in sixteenths of a round: whole rounds while there are few (the resident tiles run in lock-step); from
@@ -775,8 +780,7 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
     p.M = N * Ho * Wo;
     p.inv_HoWo = 1.0f / (float)(Ho * Wo);
     p.inv_Wo = 1.0f / (float)Wo;
-    static const bool int_div = getenv("YOLO_CONV_INTDIV") && atoi(getenv("YOLO_CONV_INTDIV"));
-    p.fast_div = p.M < (1 << 24) && !int_div;
+    p.fast_div = p.M < (1 << 24);
     p.stride = stride;
     p.ksize = k;
     const int row_elems = ROWB / es;

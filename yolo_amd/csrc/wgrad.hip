@@ -26,6 +26,8 @@
 // buffer, and every address is base + k * pixel stride.  Images are walked in segments of G consecutive
 // images (position range: first interior pixel of the first image .. last interior pixel of the last), G
 // chosen to minimise the number of 64-position k-steps.
+#include <mutex>
+
 #include "common.h"
 
 namespace yolo {
@@ -404,9 +406,8 @@ static void launch_wgrad_reduce(const void* ws, float* dw, long long n, int spli
 }
 
 static int wgrad_target_blocks(int k) {
-    static const int v1 = getenv("YOLO_WGRAD_BLOCKS1") ? atoi(getenv("YOLO_WGRAD_BLOCKS1")) : 512;
-    static const int v3 = getenv("YOLO_WGRAD_BLOCKS3") ? atoi(getenv("YOLO_WGRAD_BLOCKS3")) : 1024;
-    return k == 1 ? v1 : v3;
+    // one round of the 512 resident workgroups for the memory-bound 1x1 layers, two for 3x3 (measured optimum)
+    return k == 1 ? 512 : 1024;
 }
 
 // `steps` k-steps of 64 pixels (or positions); at most `max_splits` slabs fit the workspace.  512 workgroups are
@@ -546,7 +547,11 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     YOLO_REQUIRE(max_splits >= 1, "conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, (size_t)p.slab * sizeof(float));
     // Which walk: linear needs the same geometry on both sides and a (zero) halo in dz, and walks the halo too;
     // cursors need images at least 64 / Wo + 1 rows high and 32-bit byte offsets; divisions always work.
-    static const int force_mode = getenv("YOLO_WGRAD_MODE") ? atoi(getenv("YOLO_WGRAD_MODE")) : -1;
+#ifdef YOLO_CONV_TRACE
+    static const int force_mode = getenv("YOLO_WGRAD_MODE") ? atoi(getenv("YOLO_WGRAD_MODE")) : -1;  // measurement builds
+#else
+    constexpr int force_mode = -1;
+#endif
     const bool can_linear = stride == 1 && x->halo == dz->halo && dz->halo >= 1 && x->H == dz->H && x->W == dz->W;
     const long long x_bytes = (long long)N * gx.img_stride * 2, dz_bytes = (long long)N * gd.img_stride * 2;
     const bool can_cursor = 64 / Wo + 1 <= Ho && x_bytes < (1ll << 32) && dz_bytes < (1ll << 32);
@@ -581,16 +586,18 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     p.out = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     constexpr int LDS = 2 * 2 * 64 * 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        YOLO_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;  // dynamic-LDS limit of the six instances, raised once per process
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(attr_once, [&] {
+        const void* kerns[] = {(const void*)wgrad_kernel<false, 0>, (const void*)wgrad_kernel<true, 0>,
+                               (const void*)wgrad_kernel<false, 1>, (const void*)wgrad_kernel<true, 1>,
+                               (const void*)wgrad_kernel<false, 2>, (const void*)wgrad_kernel<true, 2>};
+        for (const void* k : kerns) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) attr_status = e;
+        }
+    });
+    YOLO_CHECK_HIP(attr_status);
     const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
     const bool narrow = Cin <= 64;
     auto kern = mode == 1 ? (narrow ? wgrad_kernel<true, 1> : wgrad_kernel<false, 1>)

@@ -8,3 +8,10 @@ from .transforms import (AffineTransform, ColorJitterTransform, HFlipTransform, 
 __all__ = ["YOLOV3DatasetMapper", "build_augmentation", "read_image", "RandomAffine", "RandomColorJitter", "LetterBox",
            "ResizeShortestEdge", "RandomFlip", "AffineTransform", "ColorJitterTransform", "LetterBoxTransform",
            "ResizeTransform", "HFlipTransform", "VFlipTransform", "NoOpTransform", "TransformList"]
+
+
+def __getattr__(name):
+    from . import augmentation_impl, transforms
+    if name in augmentation_impl._NOT_PORTED or name in transforms._NOT_PORTED:
+        return getattr(augmentation_impl if name in augmentation_impl._NOT_PORTED else transforms, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

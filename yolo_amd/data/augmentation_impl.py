@@ -176,3 +176,16 @@ class RandomFlip(Augmentation):
         if not do:
             return NoOpTransform()
         return HFlipTransform(w) if self.horizontal else VFlipTransform(h)
+
+
+_NOT_PORTED = ('RandomBlur', 'RandomGaussianBlur', 'RandomBilateralFilter', 'RandomMedianBlur', 'RandomPixelDropout')
+
+
+def __getattr__(name):
+    """The reference's blur / median / bilateral / pixel-dropout classes (yolo/data/augmentation_impl.py:48-129) are not ported: none
+    of its augmentation lists (detection_utils.py build_augmentation) uses them.  Asking for one says so instead of
+    failing with a bare ImportError."""
+    if name in _NOT_PORTED:
+        raise NotImplementedError(f"{name} of the reference's yolo/data is not ported to the device path "
+                                  "(no augmentation list of the reference uses it)")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

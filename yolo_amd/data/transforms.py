@@ -306,3 +306,16 @@ def fused_job(transforms: Sequence[Transform], src: torch.Tensor, dst: torch.Ten
             raise ValueError(f"fused_job: {type(t).__name__} cannot be folded at this position")
     return ops.aug_job(src, dst, dst_xy=dst_xy, crop=crop, border=BORDER_VALUE, planar=planar,
                        reverse_channels=reversed_source, **kw)
+
+
+_NOT_PORTED = ('BoxFilterTransform', 'BlurTransform', 'GaussianBlurTransform', 'MedianBlurTransform', 'BilateralFilterTransform', 'PixelDropoutTransform')
+
+
+def __getattr__(name):
+    """The reference's blur / median / bilateral / pixel-dropout classes (yolo/data/transforms.py:71-169) are not ported: none
+    of its augmentation lists (detection_utils.py build_augmentation) uses them.  Asking for one says so instead of
+    failing with a bare ImportError."""
+    if name in _NOT_PORTED:
+        raise NotImplementedError(f"{name} of the reference's yolo/data is not ported to the device path "
+                                  "(no augmentation list of the reference uses it)")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

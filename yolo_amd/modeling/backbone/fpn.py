@@ -240,6 +240,11 @@ def build_darknet53_fpn_backbone(cfg, input_shape):
     out_channels = (4 + 1 + num_classes) * num_anchors[0]
     fpn = DarkNetFPN(bottom_up, in_features, out_channels, norm=cfg.MODEL.DARKNET.NORM, num_classes=num_classes,
                      anchors_wh=gen.anchors_wh())
+    # The decode kernel computes anchor centres as (cell + 0.5) * stride; the training path builds its anchors from
+    # MODEL.ANCHOR_GENERATOR.OFFSET.  Any other offset would make the two disagree silently, so it is refused.
+    if float(gen.offset) != 0.5:
+        raise NotImplementedError(f"MODEL.ANCHOR_GENERATOR.OFFSET = {gen.offset}: the decode kernel is built for the "
+                                  "reference's 0.5 (configs/yolov3.yaml:13)")
     fpn.freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
     for name, p in fpn.named_parameters():  # DarkNet.freeze (reference darknet.py:236-258)
         if _frozen(name, fpn.freeze_at):

@@ -131,26 +131,17 @@ def fold_norm(weight: torch.Tensor, bias: Optional[torch.Tensor], norm: Optional
     return w, b
 
 
-def pack_conv(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, device, *,
-              patch_layout: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+def pack_conv(weight: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """[Cout,Cin,k,k] f32 -> packed [Cout_pad, K] rows in ``dtype`` + f32 bias [Cout_pad].
 
-    Default order of k inside a row: (kh, kw, cin), for yolo_conv2d_fwd; with bf16, Cin == 32, k == 3 the row is
-    padded from 9 to 10 taps (zeros) because one 128-byte k-step then spans two taps.
-    ``patch_layout``: (cin/32, kh, kw, 32), padded to an even number of 32-wide steps, for
-    yolo_conv3x3_patch_fwd.
+    Order of k inside a row: (kh, kw, cin); with bf16, Cin == 32, k == 3 the row is padded from 9 to 10 taps (zeros)
+    because one 128-byte k-step then spans two taps.
     """
     cout, cin, k, _ = weight.shape
     cpad = lib().yolo_conv_cout_pad(cout)
-    if patch_layout:
-        assert k == 3 and dtype == torch.bfloat16 and (cin == 32 or cin % 64 == 0)
-        rows = weight.reshape(cout, cin // 32, 32, k, k).permute(0, 1, 3, 4, 2).reshape(cout, k * k * cin)
-        if (cin // 32) % 2 == 1:
-            rows = torch.cat([rows, rows.new_zeros(cout, 32)], dim=1)
-    else:
-        rows = weight.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
-        if dtype == torch.bfloat16 and cin == 32 and k == 3:
-            rows = torch.cat([rows, rows.new_zeros(cout, 32)], dim=1)
+    rows = weight.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+    if dtype == torch.bfloat16 and cin == 32 and k == 3:
+        rows = torch.cat([rows, rows.new_zeros(cout, 32)], dim=1)
     wp = torch.zeros((cpad, rows.shape[1]), dtype=dtype, device=device)
     wp[:cout] = rows.to(device=device, dtype=dtype)
     bp = torch.zeros(cpad, dtype=torch.float32, device=device)
@@ -204,20 +195,6 @@ def conv2d_fwd(x: View, w_packed: torch.Tensor, bias: torch.Tensor, y: View, *, 
                                  x.N, cin, cout, k, stride, float(slope), int(upsample2x),
                                  dtype_code(x.buf.dtype), dtype_code(y.buf.dtype), _stream())
     check(code, "yolo_conv2d_fwd")
-
-
-def conv3x3_patch_fwd(x: View, w_packed: torch.Tensor, bias: torch.Tensor, y: View, *, cin: int, cout: int,
-                      slope: float = 0.1, residual: Optional[View] = None) -> None:
-    """3x3 stride-1 bf16 convolution through the LDS-resident-patch kernel (weights from
-    pack_conv(..., patch_layout=True))."""
-    _require_cuda(x.buf, "conv3x3_patch_fwd")
-    assert x.buf.dtype == torch.bfloat16 and y.buf.dtype == torch.bfloat16
-    xv, yv = x.c(), y.c()
-    rv = residual.c() if residual is not None else None
-    code = lib().yolo_conv3x3_patch_fwd(ctypes.byref(xv), _ptr(w_packed), _ptr(bias),
-                                        ctypes.byref(rv) if rv is not None else None, ctypes.byref(yv),
-                                        x.N, cin, cout, float(slope), _stream())
-    check(code, "yolo_conv3x3_patch_fwd")
 
 
 def stem_fwd(images: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: View, *,

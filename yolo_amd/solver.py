@@ -19,18 +19,23 @@ class ArenaSGD(torch.optim.SGD):
     def __init__(self, params, model=None, **kw):
         super().__init__(params, **kw)
         self._model = model
-        self._fused = None  # (engine, mom arena, block table, n blocks, [(param, mom view)])
+        self._fused = None  # (engine, mom arena, block table, n blocks, [(param, mom view)], the two groups)
+        self._fused_off = None  # (engine, reason): the one-launch step is not possible with this engine; not retried
 
     def _engine(self):
         bb = getattr(self._model, "backbone", None)
         return getattr(bb, "_train_engine", None)
 
     def _prepare(self, eng):
-        groups = self.param_groups
-        if len(groups) != 2 or any(g["nesterov"] or g["dampening"] != 0 or g["maximize"] for g in groups):
-            return None
-        if groups[0]["momentum"] != groups[1]["momentum"] or groups[0]["momentum"] == 0:
-            return None
+        """The one-launch step's state, or a string saying why it cannot be used (empty hyper-parameter groups --
+        e.g. the norm group of a model built with MODEL.DARKNET.NORM "" -- do not count)."""
+        groups = [g for g in self.param_groups if g["params"]]
+        if not 1 <= len(groups) <= 2:
+            return f"{len(groups)} non-empty parameter groups (the kernel takes one or two)"
+        if any(g["nesterov"] or g["dampening"] != 0 or g["maximize"] for g in groups):
+            return "nesterov / dampening / maximize"
+        if groups[0]["momentum"] != groups[-1]["momentum"] or groups[0]["momentum"] == 0:
+            return "momentum is zero or differs between the groups"
         arena, garena = eng.param_arena, eng.grad_arena
         base, gbase, n = arena.data_ptr(), garena.data_ptr(), arena.numel()
         segments, views, covered = [], [], 0
@@ -40,7 +45,7 @@ class ArenaSGD(torch.optim.SGD):
                 off = (prm.data_ptr() - base) // 4
                 if prm.dtype != torch.float32 or off < 0 or off + prm.numel() > n or prm.grad is None or \
                         prm.grad.data_ptr() != gbase + 4 * off:
-                    return None
+                    return "a parameter (or its .grad) lives outside the training engine's arenas"
                 # a parameter is one contiguous run of the arena, possibly permuted (conv weights are channels_last)
                 mview = torch.as_strided(mom, prm.shape, prm.stride(), off)
                 st = self.state[prm]
@@ -51,11 +56,11 @@ class ArenaSGD(torch.optim.SGD):
                 views.append((prm, mview))
                 covered += prm.numel()
         if covered != n:
-            return None
+            return "the optimizer's parameters do not cover the arena"
         segments.sort()
         from . import ops
         table, nb = ops.sgd_block_table(segments, arena.device)
-        return eng, mom, table, nb, views
+        return eng, mom, table, nb, views, (groups[0], groups[-1])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -63,18 +68,25 @@ class ArenaSGD(torch.optim.SGD):
         eng = self._engine()
         usable = closure is None and eng is not None and eng.param_arena is not None and \
             os.environ.get("YOLO_FUSED_SGD", "1") != "0"
+        if usable and self._fused_off is not None and self._fused_off[0] is eng:
+            usable = False  # already found impossible with this engine: torch's step, without preparing again
         if usable and (self._fused is None or self._fused[0] is not eng or
                        any(self.state[p].get("momentum_buffer") is not m for p, m in self._fused[4])):
-            self._fused = self._prepare(eng)
+            res = self._prepare(eng)
+            if isinstance(res, str):
+                import logging
+                logging.getLogger(__name__).warning("ArenaSGD: one-launch step disabled (%s); using torch's step", res)
+                self._fused, self._fused_off = None, (eng, res)
+            else:
+                self._fused = res
         if not usable or self._fused is None:
             self._fused = None
             return super().step(closure)
         from . import ops
-        eng, mom, table, nb, views = self._fused
+        eng, mom, table, nb, views, (g0, g1) = self._fused
         if any(p.grad is None for p, _ in views):
             self._fused = None
             return super().step(closure)
-        g0, g1 = self.param_groups
         ops.sgd_step(eng.param_arena, eng.grad_arena, mom, table, nb, g0["lr"], g0["weight_decay"], g1["lr"],
                      g1["weight_decay"], g0["momentum"])
         # in-place update outside autograd's sight: move the version counters ourselves (the engines key their
