@@ -177,74 +177,6 @@ def test_conv_rejects_bad_arguments(cuda):
 
 
 @pytest.mark.parametrize("img_dtype", [torch.float32, torch.uint8], ids=["f32img", "u8img"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_stem(cuda, dtype, img_dtype):
-    """preprocess ((x - mean)/std, zero pad to a multiple of 32) + BasicStem (darknet.py:57-60)."""
-    from yolo_amd import ops
-    g = torch.Generator().manual_seed(3)
-    N, Hs, Ws, H, W = 2, 50, 75, 64, 96
-    img = torch.randint(0, 256, (N, 3, Hs, Ws), generator=g)
-    w = torch.randn(32, 3, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
-    norm = _rand_norm(32, g)
-    mean, std = (10.0, 20.0, 30.0), (255.0, 128.0, 64.0)
-    xin = torch.zeros(N, 3, H, W)
-    xin[:, :, :Hs, :Ws] = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
-    ref = _ref_conv(xin, w, norm, None, 1, 0.1, None)
-    wf, bf = ops.fold_norm(w, None, norm)
-    ws, bs = ops.pack_stem(wf, bf, cuda)
-    yv = ops.alloc_view(N, H, W, 32, 1, dtype, cuda)
-    ops.stem_fwd(img.to(img_dtype).to(cuda).contiguous(), ws, bs, yv, mean=mean, std=std)
-    torch.cuda.synchronize()
-    got = yv.nchw().float().cpu()
-    assert _rel_err(got, ref) < (FP32_TOL if dtype == torch.float32 else BF16_TOL)
-
-
-def test_conv_rejects_bad_arguments(cuda):
-    from yolo_amd import ops
-    from yolo_amd._lib import YoloHipError
-    x = ops.alloc_view(1, 4, 4, 64, 0, torch.bfloat16, cuda)  # halo 0 < pad 1
-    y = ops.alloc_view(1, 4, 4, 64, 1, torch.bfloat16, cuda)
-    w = torch.zeros(128, 9 * 64, dtype=torch.bfloat16, device=cuda)
-    b = torch.zeros(128, device=cuda)
-    with pytest.raises(YoloHipError, match="halo"):
-        ops.conv2d_fwd(x, w, b, y, cin=64, cout=64, k=3, stride=1)
-    x2 = ops.alloc_view(1, 4, 4, 48, 1, torch.bfloat16, cuda)
-    with pytest.raises(YoloHipError, match="Cin"):
-        ops.conv2d_fwd(x2, w, b, y, cin=48, cout=64, k=1, stride=1)
-
-
-# (Cin, Cout, H, W): small images use whole-row patches, wide ones 2-D blocks; 32 channels = single slice
-PATCH_SHAPES = [(32, 64, 24, 208), (64, 128, 20, 104), (128, 256, 13, 52), (256, 512, 26, 26), (512, 1024, 13, 13),
-                (64, 64, 7, 5), (128, 128, 40, 136)]
-
-
-@pytest.mark.parametrize("shape", PATCH_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_conv3x3_patch_kernel(cuda, shape):
-    """Opt-in LDS-resident-patch kernel (yolo_conv3x3_patch_fwd) against the same torch reference, with a
-    residual, incl. pixel tiles that span image rows and images, 2-D block tiles and ragged edges."""
-    from yolo_amd import ops
-    cin, cout, H, W = shape
-    g = torch.Generator().manual_seed(cin * 7 + W)
-    N = 3
-    x = torch.randn(N, cin, H, W, generator=g)
-    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
-    norm = _rand_norm(cout, g)
-    res = torch.randn(N, cout, H, W, generator=g)
-    wf, bf = ops.fold_norm(w, None, norm)
-    ref = _ref_conv(x.bfloat16().float(), wf.bfloat16().float(), None, bf, 1, 0.1, res.bfloat16().float())
-    wp, bp = ops.pack_conv(wf, bf, torch.bfloat16, cuda, patch_layout=True)
-    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
-    rv = ops.view_from_nchw(res.to(cuda), 1, torch.bfloat16)
-    yv = ops.alloc_view(N, H, W, cout, 1, torch.bfloat16, cuda)
-    ops.conv3x3_patch_fwd(xv, wp, bp, yv, cin=cin, cout=cout, residual=rv)
-    torch.cuda.synchronize()
-    got = yv.nchw().float().cpu()
-    assert _rel_err(got, ref) < BF16_TOL
-    assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
-    assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, -1].abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("img_dtype", [torch.float32, torch.uint8], ids=["f32img", "u8img"])
 @pytest.mark.parametrize("geom", [(2, 50, 75, 64, 96), (3, 96, 160, 96, 160), (1, 33, 47, 64, 64)],
                          ids=lambda g_: "x".join(map(str, g_)))
 def test_stem_down_fused(cuda, geom, img_dtype):
