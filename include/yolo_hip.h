@@ -160,6 +160,26 @@ int yolo_decode(const yolo_view* head, int L, const int* stride_host, const floa
 size_t yolo_decode_workspace_bytes(const yolo_view* head, int L, int N);
 
 /*
+ * yolo_decode without a workspace argument, for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments, launches and results as yolo_decode; the per-cell counts / offsets and per-image totals live in a device
+ * array built into the library (4.02 MiB, held by every GPU the library runs on until the process ends).  The call
+ * allocates and frees nothing; the first call on a device looks up that device's copy of the array
+ * (hipGetSymbolAddress), so make it once outside a graph capture.
+ *   limits      N * (grid cells per image, all levels) <= YOLO_DECODE_NOALLOC_MAX_SLOTS and
+ *               N <= YOLO_DECODE_NOALLOC_MAX_BATCH (batch 64 at 608 x 608 is 485,184 slots); beyond them the call
+ *               fails with YOLO_E_ARG and a message naming yolo_decode
+ *   concurrency every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ *               threads) race; calls on one stream, or on different GPUs, do not.  Nothing of an earlier call's
+ *               contents is read.
+ */
+#define YOLO_DECODE_NOALLOC_MAX_SLOTS (512 * 1024)
+#define YOLO_DECODE_NOALLOC_MAX_BATCH 4096
+int yolo_decode_noalloc(const yolo_view* head, int L, const int* stride_host, const float* anchors_wh_host,
+                        int N, int A, int C, float thr, int head_dtype,
+                        float* boxes, float* scores, int* classes, int* img_offsets, int cap, void* stream);
+
+/*
  * Batched per-class NMS over all images.  Replaces batched_nms(boxes, scores, classes, thr) at
  * yolo/modeling/meta_arch/yolo.py:305 (detectron2.layers.batched_nms -> torchvision batched_nms ->
  * torchvision::nms) and the keep[:max_detections] truncation at :307.

@@ -105,6 +105,8 @@ SIGNATURES = {
     "yolo_decode": (c_int, [_VP, c_int, _IP, _FP, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "yolo_decode_workspace_bytes": (c_size_t, [_VP, c_int, c_int]),
+    "yolo_decode_noalloc": (c_int, [_VP, c_int, _IP, _FP, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_void_p]),
     "yolo_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_int,
                                  c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),

@@ -17,6 +17,8 @@
 // touches only cells that produced candidates.
 //
 // Built with -ffp-contract=off: the box arithmetic keeps the reference's rounding sequence.
+#include <mutex>
+
 #include "common.h"
 
 namespace yolo {
@@ -317,9 +319,9 @@ extern "C" size_t yolo_decode_workspace_bytes(const yolo_view* head, int L, int 
     return 2 * align256(cells * sizeof(int)) + align256((size_t)N * sizeof(int));
 }
 
-extern "C" int yolo_decode(const yolo_view* head, int L, const int* stride_host, const float* anchors_wh_host, int N,
-                           int A, int C, float thr, int head_dtype, float* boxes, float* scores, int* classes,
-                           int* img_offsets, int cap, void* workspace, size_t ws_bytes, void* stream) {
+static int decode_impl(const yolo_view* head, int L, const int* stride_host, const float* anchors_wh_host, int N,
+                       int A, int C, float thr, int head_dtype, float* boxes, float* scores, int* classes,
+                       int* img_offsets, int cap, void* workspace, size_t ws_bytes, void* stream) {
     YOLO_REQUIRE(head && stride_host && anchors_wh_host && boxes && scores && classes && img_offsets && workspace,
                  "decode: null argument");
     YOLO_REQUIRE(L >= 1 && L <= MAX_LEVELS, "decode: %d levels (1..%d)", L, MAX_LEVELS);
@@ -392,4 +394,66 @@ extern "C" int yolo_decode(const yolo_view* head, int L, const int* stride_host,
     }
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
+}
+
+extern "C" int yolo_decode(const yolo_view* head, int L, const int* stride_host, const float* anchors_wh_host, int N,
+                           int A, int C, float thr, int head_dtype, float* boxes, float* scores, int* classes,
+                           int* img_offsets, int cap, void* workspace, size_t ws_bytes, void* stream) {
+    return decode_impl(head, L, stride_host, anchors_wh_host, N, A, C, thr, head_dtype, boxes, scores, classes,
+                       img_offsets, cap, workspace, ws_bytes, stream);
+}
+
+// ---- yolo_decode_noalloc: the same launches with the workspace in a device array of this code object -----------------
+//
+// For callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc).  The per-cell counts, per-cell offsets and per-image totals of yolo_decode live in `scratch`, a
+// file-scope device array that every GPU the library runs on holds (at its own address) until the process ends.
+// In host code the array's NAME is only a stand-in; its address on the current device comes from
+// hipGetSymbolAddress, once per device, and only that pointer is handed to the kernels.
+namespace yolo {
+
+constexpr long long NOALLOC_MAX_SLOTS = YOLO_DECODE_NOALLOC_MAX_SLOTS;  // batch x grid cells per image
+constexpr int NOALLOC_MAX_BATCH = YOLO_DECODE_NOALLOC_MAX_BATCH;
+constexpr size_t NOALLOC_BYTES = 2 * NOALLOC_MAX_SLOTS * sizeof(int) + NOALLOC_MAX_BATCH * sizeof(int);  // 4.02 MiB
+
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex scratch_mutex;
+static void* scratch_ptr[MAX_DEVICES];  // per device: address of that GPU's copy of `scratch` (null = not asked yet)
+
+// Address of the current device's copy of `scratch`; resolved on the first call on that device.
+static int scratch_of_current_device(void** out) {
+    int dev = -1;
+    YOLO_CHECK_HIP(hipGetDevice(&dev));
+    YOLO_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "decode_noalloc: device index %d (0..%d)", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        YOLO_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        YOLO_REQUIRE(ptr != nullptr, "decode_noalloc: the scratch array has no address on device %d", dev);
+        scratch_ptr[dev] = ptr;
+    }
+    *out = scratch_ptr[dev];
+    return YOLO_OK;
+}
+
+}  // namespace yolo
+
+extern "C" int yolo_decode_noalloc(const yolo_view* head, int L, const int* stride_host, const float* anchors_wh_host,
+                                   int N, int A, int C, float thr, int head_dtype, float* boxes, float* scores,
+                                   int* classes, int* img_offsets, int cap, void* stream) {
+    YOLO_REQUIRE(head && L >= 1 && L <= MAX_LEVELS && N >= 1, "decode_noalloc: bad argument");
+    const long long slots = (long long)cells_per_image(head, L) * N;
+    YOLO_REQUIRE(slots <= NOALLOC_MAX_SLOTS && N <= NOALLOC_MAX_BATCH,
+                 "decode_noalloc: batch %d x %d grid cells = %lld slots exceeds the built-in scratch (%lld slots, batch <= %d); "
+                 "use yolo_decode with a caller-owned workspace",
+                 N, cells_per_image(head, L), slots, NOALLOC_MAX_SLOTS, NOALLOC_MAX_BATCH);
+    void* ptr = nullptr;
+    const int rc = scratch_of_current_device(&ptr);
+    if (rc != YOLO_OK) return rc;
+    // every scratch word the kernels read is written earlier in the same call (a count for every cell, an offset for
+    // every cell, a total for every image): nothing has to start at zero, and what the last call left is never read
+    return decode_impl(head, L, stride_host, anchors_wh_host, N, A, C, thr, head_dtype, boxes, scores, classes, img_offsets,
+                       cap, ptr, NOALLOC_BYTES, stream);
 }

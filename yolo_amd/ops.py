@@ -303,6 +303,22 @@ def decode(heads: List[View], strides: Sequence[int], anchors_wh: Sequence[Seque
     return out
 
 
+def decode_noalloc(heads: List[View], strides: Sequence[int], anchors_wh: Sequence[Sequence[Tuple[float, float]]],
+                   num_classes: int, thr: float, out: Candidates) -> Candidates:
+    """``decode`` through yolo_decode_noalloc: no workspace tensor, nothing allocated by the call (the caller owns
+    ``out``); batch x grid cells is limited by the library's built-in scratch array."""
+    _require_cuda(heads[0].buf, "decode_noalloc")
+    N, L, A = heads[0].N, len(heads), len(anchors_wh[0])
+    st = (ctypes.c_int * L)(*[int(s) for s in strides])
+    flat = [float(v) for lvl in anchors_wh for wh in lvl for v in wh]
+    an = (ctypes.c_float * len(flat))(*flat)
+    check(lib().yolo_decode_noalloc(_views_array(heads), L, st, an, N, A, num_classes, float(thr),
+                                    dtype_code(heads[0].buf.dtype), _ptr(out.boxes), _ptr(out.scores),
+                                    _ptr(out.classes), _ptr(out.img_offsets), out.scores.numel(), _stream()),
+          "yolo_decode_noalloc")
+    return out
+
+
 def nms_workspace_bytes(N: int, M: int) -> int:
     return int(lib().yolo_nms_workspace_bytes(N, M))
 
