@@ -83,6 +83,12 @@ int yolo_conv_cout_pad(int Cout);
  * yolo_conv2d_fwd uses for M = N*Ho*Wo output pixels and Cout channels, i.e. which kernel instance runs. */
 int yolo_conv_tile_shape(int M, int Cin, int Cout, int k, int dtype, int* tile_channels, int* tile_pixels);
 
+/* Introspection for benchmarks and profilers: a short name of the kernel instance yolo_conv2d_fwd launches for this
+ * convolution, "conv_igemm_kernel<dtype,tile channels,tile pixels,wave layout,form>" with form = plain | tap2 | strip
+ * (strip: the 3x3 / stride-1 form whose three kw taps share one staged strip of pixel rows). */
+int yolo_conv_kernel_name(const yolo_view* x, const yolo_view* y, int N, int Cin, int Cout, int k, int stride,
+                          int upsample2x, int dtype, char* out, int out_len);
+
 /*
  * First layer: pixel normalisation + zero padding + 3x3/s1 stem conv + bias + LeakyReLU.
  * Replaces DenseDetector.preprocess_image (driven by configs/yolov3.yaml:5-6 and fpn.py:161-163)

@@ -90,6 +90,50 @@ def test_conv_shapes(cuda, shape, dtype):
     assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, 0].abs().max()) == 0.0
 
 
+# (Cin, Cout, N, H, W, residual, y halo, y channel offset / total): 3x3 stride-1 bf16 layers wide enough for the strip
+# form (the three kw taps share one staged strip; pixels enumerated with their halo columns).  Tiles that span image
+# rows and images, a ragged last tile, one image smaller than a tile, output into a channel slice, no halo in y.
+STRIP_SHAPES = [
+    (64, 128, 3, 9, 43, True, 1, (0, 128)), (128, 256, 2, 7, 41, True, 1, (128, 384)), (256, 512, 2, 30, 46, False, 1, (0, 512)),
+    (128, 128, 5, 4, 40, True, 0, (0, 128)), (512, 1024, 1, 3, 60, False, 1, (0, 1024)), (64, 255, 2, 11, 53, False, 0, (0, 256)),
+    (128, 256, 1, 52, 52, True, 1, (0, 256)),
+]
+
+
+@pytest.mark.parametrize("shape", STRIP_SHAPES, ids=lambda s: "x".join(map(str, s[:5])))
+def test_conv_strip_form(cuda, shape):
+    from yolo_amd import ops
+    cin, cout, N, H, W, use_res, yhalo, (choff, chtot) = shape
+    g = torch.Generator().manual_seed(cin + 3 * W)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    norm = _rand_norm(cout, g)
+    res = torch.randn(N, cout, H, W, generator=g) if use_res else None
+    wf, bf = ops.fold_norm(w, None, norm)
+    ref = _ref_conv(x.bfloat16().float(), wf.bfloat16().float(), None, bf, 1, 0.1,
+                    res.bfloat16().float() if use_res else None)
+    wp, bp = ops.pack_conv(wf, bf, torch.bfloat16, cuda)
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    ybuf = ops.alloc_view(N, H, W, chtot, yhalo, torch.bfloat16, cuda)
+    ybuf.buf.fill_(7.0)
+    yv = ybuf.slice(choff, (cout + 7) // 8 * 8)
+    rv = ops.view_from_nchw(res.to(cuda), 0, torch.bfloat16) if use_res else None
+    assert "strip" in ops.conv_kernel_name(xv, yv, cin, cout, 3, 1)
+    ops.conv2d_fwd(xv, wp, bp, yv, cin=cin, cout=cout, k=3, stride=1, residual=rv)
+    torch.cuda.synchronize()
+    got = yv.nchw()[:, :cout].float().cpu()
+    assert _rel_err(got, ref) < BF16_TOL
+    assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    # nothing outside the output slice's interior was written: halo and the other channels keep the fill value
+    full = ybuf.buf.float().cpu()
+    if yhalo:
+        assert bool((full[:, 0] == 7.0).all() and (full[:, -1] == 7.0).all())
+        assert bool((full[:, :, 0] == 7.0).all() and (full[:, :, -1] == 7.0).all())
+    keep = torch.ones(chtot, dtype=torch.bool)
+    keep[choff:choff + (cout + 7) // 8 * 8] = False
+    assert bool((full[..., keep] == 7.0).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_concat_slice_and_upsample(cuda, dtype):
     """UpSampleBlock + torch.cat (fpn.py:33-37,179): conv output written 2x-upsampled into channels

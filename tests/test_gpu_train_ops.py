@@ -229,7 +229,9 @@ def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
 def test_stride2_dgrad_without_dilation(cuda, shape, with_residual):
     """yolo_conv3x3s2_dgrad against the form it replaces, yolo_dilate2x_nhwc + yolo_conv2d_fwd with the same
     data-gradient weights: the same products are summed in the same order (the dilated form only adds zeros), so
-    the two agree bit for bit; and against torch's conv_transpose2d on the bf16-rounded operands."""
+    the two agree bit for bit -- unless the stride-1 convolution of the dilated form runs in its strip form, which
+    sums the taps in another order: then to one bf16 rounding; and against torch's conv_transpose2d on the
+    bf16-rounded operands."""
     from yolo_amd import ops
     N, c_in, c_out, Hi, Wi = shape            # forward conv: c_in -> c_out, 3x3, stride 2; dz has c_out channels
     torch.manual_seed(23)
@@ -251,7 +253,11 @@ def test_stride2_dgrad_without_dilation(cuda, shape, with_residual):
     got.buf.fill_(5.0)
     ops.conv3x3s2_dgrad(dz, wd, bd, got, cin=cpad, cout=c_in, residual=res)
     torch.cuda.synchronize()
-    assert torch.equal(got.interior(), want.interior())
+    if "strip" in ops.conv_kernel_name(dzd, want, cpad, c_in, 3, 1):
+        a, b = got.interior().float(), want.interior().float()
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+    else:
+        assert torch.equal(got.interior(), want.interior())
     assert float(got.buf[:, 0].min()) == 5.0 and float(got.buf[:, :, 0].min()) == 5.0   # the halo is not written
     ref = F.conv_transpose2d(dz.nchw()[:, :c_out].float().cpu(), w.bfloat16().float(), stride=2, padding=1, output_padding=1)
     if with_residual:

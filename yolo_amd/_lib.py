@@ -58,6 +58,7 @@ SIGNATURES = {
     "yolo_abi_version": (c_int, []),
     "yolo_conv_cout_pad": (c_int, [c_int]),
     "yolo_conv_tile_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, _IP, _IP]),
+    "yolo_conv_kernel_name": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
     "yolo_conv2d_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_int, c_int, c_void_p]),
     "yolo_stem_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p, c_void_p, _VP,
@@ -118,20 +119,31 @@ SIGNATURES = {
 _lib = None
 
 
+def load(path: str) -> ctypes.CDLL:
+    """A handle of the library at ``path`` with every entry point's signature set."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `make -C yolo_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `make -C yolo_amd/csrc` (or "
-                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = load(LIB_PATH)
     return _lib
+
+
+def use(handle: ctypes.CDLL) -> None:
+    """Route every operator through another build of the library (A/B measurements in one process)."""
+    global _lib
+    _lib = handle
 
 
 class YoloHipError(RuntimeError):

@@ -49,6 +49,7 @@ struct ConvParams {
     int upsample;
     int y_f32;  // output element type is f32 (else bf16)
     int Mc;        // S2D kernels: pixels per parity class (N * Hi * Wi); n_ptiles = 4 * tiles per class
+    int Wreal;     // STRIP kernels: real output width; p.Wo is then the row length INCLUDING the two halo columns
     float* stats;  // STATS kernels: per pixel tile, per channel: [n_ptiles][2][Cout] sums of y and y*y
 };
 
@@ -116,12 +117,27 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // (one for a = 0, two for a = 1; likewise kw'), at dz row i + (a+kh'-1)/2.  The pixels of a launch are
 // enumerated class by class ((a,b) = 00, 01, 10, 11), every tile lies inside one class and runs 1, 2, 2 or 4 of
 // the 9 taps: 9 tap-visits per 4 output pixels instead of 36.  p.Ho/p.Wo/p.Mc describe ONE class (= dz's grid).
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false>
+//
+// STRIP: 3x3 / stride-1 / pad-1 convolution whose three kw taps share ONE staged strip of pixel rows.  The pixels of
+// a launch are enumerated over the rows of the halo'd input INCLUDING their two halo columns ("positions":
+// v = (n * H + row) * (W + 2) + column, column 0 and W + 1 being halo); consecutive positions are consecutive pixels in
+// memory, so the tap (kh, kw) of position v is the pixel of position v + kw - 1 one buffer row further down per kh.
+// Per (kh, 64-channel chunk) the workgroup stages ONE strip of TP + 2 pixel rows and reads it three times at row
+// offsets 0, 1, 2; only the weights change per k-step: (3 * TC + TP + 2) * 128 bytes cross the L2 -> LDS path per
+// three k-steps instead of 3 * (TC + TP) * 128.  Outputs at the halo columns (2 of W + 2) are computed and dropped.
+// The k order is (kh, channel chunk, kw); the weights stay packed (kh, kw, channel).  p.Ho / p.Wo / p.M describe the
+// position grid (H, W + 2, N * H * (W + 2)); p.Wreal is W.
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
+          bool STRIP = false>
 __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(const ConvParams p) {
     static_assert(!(S2D && (TAP2 || STATS)), "S2D is a plain bf16/f32 convolution");
+    static_assert(!(STRIP && (TAP2 || S2D || STATS || sizeof(T) != 2)), "STRIP is a plain bf16 3x3 convolution");
     static_assert(WC * WP == NW, "waves");
     constexpr bool BF = sizeof(T) == 2;
-    constexpr int W_BYTES = TC * ROWB, X_BYTES = TP * ROWB, BUF = W_BYTES + X_BYTES;
+    constexpr int SP = (TP + 2 + 7) / 8;          // STRIP: 1-KiB pieces (8 pixel rows) of a strip
+    constexpr int NXS = (SP + NW - 1) / NW;       // STRIP: strip pieces per wave
+    constexpr int XS_BYTES = SP * 1024;
+    constexpr int W_BYTES = TC * ROWB, X_BYTES = STRIP ? XS_BYTES : TP * ROWB, BUF = W_BYTES + X_BYTES;
     constexpr int FC = TC / (16 * WC), FP = TP / (16 * WP);
     constexpr int NWP = TC / (8 * NW), NXP = TP / (8 * NW);  // 1-KiB pieces per wave per operand
     static_assert(TC % (8 * NW) == 0 && TP % (8 * NW) == 0, "whole pieces per wave");
@@ -168,7 +184,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     const int lrow = lane >> 3;
     const int schunk = (lane & 7) ^ lrow;  // source chunk; LDS chunk (lane&7) of row r holds chunk (lane&7)^(r&7)
     const char* wsrc[NWP];
-    const char* xsrc[NXP];
+    const char* xsrc[STRIP ? NXS : NXP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
         const int row = 8 * (wave + NW * i) + lrow;
@@ -180,17 +196,23 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         constexpr int STEP = 8 * NW;
         const int xs_rows = STEP / p.Wo, xs_cols = STEP - xs_rows * p.Wo;
         const bool xtiny = xs_rows + 1 > p.Ho;  // images smaller than a step: split every row
-        const int mfirst = pix_base + 8 * wave + lrow;
+        // STRIP: strip row r is position pix_base - 1 + r (the tile's first output needs its left neighbour)
+        const int mfirst = pix_base + 8 * wave + lrow - (STRIP ? 1 : 0);
+        const int mclamp = mfirst < 0 ? 0 : mfirst;
         int n, ho, wo;
-        split_pixel(p, mfirst < pix_end ? mfirst : pix_end - 1, HoWo, n, ho, wo);
+        split_pixel(p, mclamp < pix_end ? mclamp : pix_end - 1, HoWo, n, ho, wo);
         const char* first = nullptr;
+        constexpr int NX = STRIP ? NXS : NXP;
 #pragma unroll
-        for (int i = 0; i < NXP; ++i) {
+        for (int i = 0; i < NX; ++i) {
             const char* a = p.x + p.x_origin + (long long)n * p.x_img_stride + (long long)(ho * p.stride) * p.x_row_stride +
                             (wo * p.stride) * p.x_pix_stride + (TAP2 ? (schunk & 3) : schunk) * 16;
-            if (i == 0) first = a;
+            if (i == 0) {
+                first = a;
+                if (STRIP && mfirst < 0) --wo;  // position -1 read position 0 (its output is a halo column); step on from -1
+            }
             xsrc[i] = mfirst + STEP * i < pix_end ? a : first;  // tail rows read a valid pixel; never stored
-            if (i + 1 < NXP) {
+            if (i + 1 < NX) {
                 if (xtiny) {
                     const int m = mfirst + STEP * (i + 1);
                     split_pixel(p, m < pix_end ? m : pix_end - 1, HoWo, n, ho, wo);
@@ -244,6 +266,22 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         }
     };
 
+    // STRIP stagers: the weights of one k-step; one third (PART = 0..2, or all: -1) of the strip of (kh, chunk cc)
+    [[maybe_unused]] auto stage_w = [&](char* wbuf, int kh, int kw, int cc) {
+        const int woff = ((kh * 3 + kw) * p.cpt + cc) * ROWB;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, wbuf + (wave + NW * i) * 1024);
+    };
+    [[maybe_unused]] auto stage_x = [&](char* xbuf, int kh, int cc, auto part_c) {
+        constexpr int PART = decltype(part_c)::value;
+        const int xoff = kh * p.x_row_stride + cc * ROWB;
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) {
+            if (PART >= 0 && i % 3 != PART) continue;
+            if (wave + NW * i < SP) glds16(xsrc[i] + xoff, xbuf + (wave + NW * i) * 1024);
+        }
+    };
+
     // ---- fragment addressing
     const int wc = wave / WP, wp = wave % WP;
     const int l15 = lane & 15, q = lane >> 4, l7 = lane & 7;
@@ -263,6 +301,33 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 
     // All fragment reads of a k-step (2 sub-steps of 32 k) are issued up front; the second half lands
     // while the matrix cores work on the first.
+    // STRIP: weights and strip live in separate buffers; tap kw reads the strip KW rows further down, and the
+    // swizzle term follows the row actually read.
+    [[maybe_unused]] auto compute_strip = [&](const char* wbuf, const char* xbuf, auto kw_c) {
+        constexpr int KW = decltype(kw_c)::value;
+        const int kb0 = (q ^ ((l15 + KW) & 7)) << 4;
+        const char* xb = xbuf + (wp * (TP / WP) + l15 + KW) * ROWB;
+        bf16x8 a[2][FC], b[2][FP];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ko = kk ? ko1 : ko0;
+            const int kb = kk ? (kb0 ^ 64) : kb0;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) a[kk][i] = *(const bf16x8*)(wbuf + a_base + i * 16 * ROWB + ko);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(xb + j * 16 * ROWB + kb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
     auto compute = [&](const char* buf) {
         if constexpr (BF) {
             bf16x8 a[2][FC], b[2][FP];
@@ -309,6 +374,54 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     // ---- main loop: loads of step s+1 fly while step s is multiplied
     const int nsteps = S2D ? (1 + par_a) * (1 + par_b) * p.cpt : p.nsteps;
     TRACE_MARK(9);
+    if constexpr (STRIP) {
+        // LDS: two weight buffers, then two strip buffers.  Group g = (kh, cc) runs three k-steps (kw = 0, 1, 2) on one
+        // strip; while it runs, the next step's weights and a third of the next group's strip are in flight.
+        char* const wb0 = smem;
+        char* const xb0 = smem + 2 * W_BYTES;
+        const int ngroups = 3 * p.cpt;
+        int kh = 0, cc = 0;        // current group
+        stage_x(xb0, 0, 0, std::integral_constant<int, -1>{});
+        stage_w(wb0, 0, 0, 0);
+        for (int g = 0; g < ngroups; ++g) {
+            int nkh = kh, ncc = cc + 1;  // next group
+            if (ncc == p.cpt) {
+                ncc = 0;
+                ++nkh;
+            }
+            const bool more = g + 1 < ngroups;
+            const char* xcur = xb0 + (g & 1) * XS_BYTES;
+            char* xnext = xb0 + ((g + 1) & 1) * XS_BYTES;
+            // the three steps of a group alternate the weight buffers starting from (3 * g) & 1 = g & 1
+            char* const wA = wb0 + (g & 1) * W_BYTES;
+            char* const wB = wb0 + ((g + 1) & 1) * W_BYTES;
+            // kw = 0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#ifdef YOLO_CONV_TRACE
+            if (g == 0) TRACE_MARK(1);
+#endif
+            stage_w(wB, kh, 1, cc);
+            if (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 0>{});
+            compute_strip(wA, xcur, std::integral_constant<int, 0>{});
+            // kw = 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stage_w(wA, kh, 2, cc);
+            if (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 1>{});
+            compute_strip(wB, xcur, std::integral_constant<int, 1>{});
+            // kw = 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (more) {
+                stage_w(wB, nkh, 0, ncc);
+                stage_x(xnext, nkh, ncc, std::integral_constant<int, 2>{});
+            }
+            compute_strip(wA, xcur, std::integral_constant<int, 2>{});
+            kh = nkh;
+            cc = ncc;
+        }
+    } else {
     stage(smem);
     for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -319,12 +432,13 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         if (s + 1 < nsteps) stage(smem + ((s + 1) & 1) * BUF);
         compute(smem + (s & 1) * BUF);
     }
+    }
     TRACE_MARK(2);
     // ---- epilogue 1: LeakyReLU in registers, f32 tile -> LDS as [pixel][channel], 16-byte chunks XOR-swizzled by
     //      (pixel & 7); epilogue 2: one lane = 8 channels of one pixel, whole pixel rows leave as contiguous bytes.
     //      A tile whose f32 image would not fit the operand buffers goes through in two halves (each wave's first
     //      and second half of pixel columns).
-    constexpr int NH = TP * TC * 4 > 2 * BUF ? 2 : 1;
+    constexpr int NH = STRIP ? 1 : (TP * TC * 4 > 2 * BUF ? 2 : 1);  // (STRIP launches with LDS for the whole f32 tile)
     constexpr int HP = TP / NH;
     constexpr int G = TC / 8;       // 8-channel groups per pixel
     constexpr int PPP = NW * 64 / G;  // pixels per pass
@@ -381,8 +495,17 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             }
         }
     };
+    auto real_col = [&](int wo) {  // STRIP: position column -> pixel column, clamped (halo-column lanes store nothing)
+        if constexpr (STRIP) {
+            const int c = wo - 1;
+            return c < 0 ? 0 : (c >= p.Wreal ? p.Wreal - 1 : c);
+        } else {
+            return wo;
+        }
+    };
+    auto is_real = [&](int wo) { return !STRIP || (wo >= 1 && wo <= p.Wreal); };
     auto res_offset = [&](int n, int ho, int wo) {
-        const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : wo;
+        const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : real_col(wo);
         return p.r_origin + (long long)n * p.r_img_stride + (long long)oh * p.r_row_stride + ow * p.r_pix_stride +
                (long long)ch_first * (int)sizeof(T);
     };
@@ -431,7 +554,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     __syncthreads();
     TRACE_MARK(5 + 2 * half);
     // the staged values are fetched GP passes at a time
-    constexpr int GP = NP <= 6 ? NP : (NP % 4 == 0 ? 4 : 1);
+    constexpr int GP = NP <= 6 ? NP : (NP % 5 == 0 ? 5 : (NP % 4 == 0 ? 4 : 1));
     static_assert(NP % GP == 0, "whole groups of passes");
     auto store_passes = [&](auto fast_c, auto res_c, auto f32out_c) {
         constexpr bool FAST = decltype(fast_c)::value, RES = decltype(res_c)::value, YF = decltype(f32out_c)::value;
@@ -448,9 +571,9 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             }
 #pragma unroll
             for (int pass = g0; pass < g0 + GP; ++pass) {
-                const bool lv = pixel_of_pass(pass) < pix_end && ch_first < p.Cout;
+                const bool lv = pixel_of_pass(pass) < pix_end && ch_first < p.Cout && is_real(wo);
                 f32x4 v0 = sv0[pass - g0], v1 = sv1[pass - g0];
-                const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : wo;
+                const int oh = S2D ? 2 * ho + par_a : ho, ow = S2D ? 2 * wo + par_b : real_col(wo);
                 if constexpr (FAST) {
                     if constexpr (RES) {
                         const u32x4 r = rres[pass];
@@ -590,17 +713,20 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     }
 }
 
-template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false>
+template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
+          bool STRIP = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-    // two operand buffers, or the f32 epilogue staging tile if that is larger
-    constexpr int OPS = 2 * (TC + TP) * ROWB, STG = TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4;
+    // two operand buffers, or the f32 epilogue staging tile if that is larger (STRIP: two weight buffers + two strips
+    // of ceil((TP + 2) / 8) KiB, and the staging tile whole)
+    constexpr int OPS = STRIP ? 2 * TC * ROWB + 2 * ((TP + 2 + 7) / 8) * 1024 : 2 * (TC + TP) * ROWB;
+    constexpr int STG = STRIP ? TP * TC * 4 : (TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4);
     constexpr int LDS0 = OPS > STG ? OPS : STG;
 #ifdef YOLO_CONV_TRACE
     static const int LDS = getenv("YOLO_CONV_LONE") ? 100 * 1024 : LDS0;  // one workgroup per CU (measurement)
 #else
     constexpr int LDS = LDS0;
 #endif
-    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D>;
+    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D, STRIP>;
     // the kernel's dynamic-LDS limit is raised once per instance (and process), whichever thread launches first
     static std::once_flag attr_once;
     static hipError_t attr_status = hipSuccess;
@@ -664,6 +790,18 @@ static int pick_tp(int M, int n_ctiles, int nsteps) {
 }
 
 static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+// The strip form (kw taps share one staged strip, 128 x 160 tile) serves 3x3 / stride-1 bf16 layers with a one-pixel
+// halo in the input and at least 128 output channels.  It computes (and drops) the two halo columns of every row, so
+// narrow images pay more for it than it saves.
+#ifndef YOLO_STRIP_MIN_W
+#define YOLO_STRIP_MIN_W 40
+#endif
+constexpr int STRIP_TP = 160;
+static bool use_strip(int dtype, int Cin, int Cout, int k, int stride, int x_halo, int W, bool upsample, bool stats) {
+    return dtype == YOLO_BF16 && k == 3 && stride == 1 && Cin % 64 == 0 && Cout > 64 && x_halo == 1 && !upsample && !stats &&
+           W >= YOLO_STRIP_MIN_W;
+}
 
 static int conv_nsteps(int Cin, int k, int dtype) {
     if (dtype == YOLO_BF16 && Cin == 32 && k == 3) return 5;
@@ -807,8 +945,41 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
         p.stats = stats;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (use_strip(dtype, Cin, Cout, k, stride, x->halo, x->W, upsample2x != 0, stats != nullptr)) {
+        // pixels are enumerated as positions of the halo'd rows (see the kernel's comment); with a one-pixel halo
+        // p.x_origin (logical pixel (-1, -1)) is the buffer's first pixel, which is position (row 0, column 0) at kh = 0
+        const int Wv = Wo + 2;
+        YOLO_REQUIRE((long long)N * Ho * Wv < (1ll << 31), "conv2d: too many output positions");
+        p.Wreal = Wo;
+        p.Wo = Wv;
+        p.M = N * Ho * Wv;
+        p.inv_HoWo = 1.0f / (float)(Ho * Wv);
+        p.inv_Wo = 1.0f / (float)Wv;
+        p.fast_div = p.M < (1 << 24);
+        p.n_ctiles = (Cout + 127) / 128;
+        p.n_ptiles = (p.M + STRIP_TP - 1) / STRIP_TP;
+        return launch_conv<bf16_t, 128, STRIP_TP, 2, 2, false, 4, false, false, true>(p, st);
+    }
     if (dtype == YOLO_BF16) return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st);
     return dispatch_tc<float, false>(p, tc, st);
+}
+
+extern "C" int yolo_conv_kernel_name(const yolo_view* x, const yolo_view* y, int N, int Cin, int Cout, int k, int stride,
+                                     int upsample2x, int dtype, char* out, int out_len) {
+    YOLO_REQUIRE(x && y && out && out_len > 0 && N > 0 && Cin > 0 && Cout > 0, "conv_kernel_name: bad argument");
+    const int up = upsample2x ? 2 : 1;
+    const int Ho = y->H / up, Wo = y->W / up;
+    const char* dt = dtype == YOLO_BF16 ? "bf16" : "float";
+    if (use_strip(dtype, Cin, Cout, k, stride, x->halo, x->W, upsample2x != 0, false)) {
+        snprintf(out, (size_t)out_len, "conv_igemm_kernel<%s,128,%d,2,2,strip>", dt, STRIP_TP);
+        return YOLO_OK;
+    }
+    int tc, tp;
+    conv_tile(N * Ho * Wo, Cin, Cout, k, dtype, &tc, &tp);
+    const bool tap2 = dtype == YOLO_BF16 && Cin == 32 && k == 3;
+    snprintf(out, (size_t)out_len, "conv_igemm_kernel<%s,%d,%d,%s,%s>", dt, tc, tp, tc == 32 ? "1,4" : "2,2",
+             tap2 ? "tap2" : "plain");
+    return YOLO_OK;
 }
 
 extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const float* bias,

@@ -160,14 +160,12 @@ def conv_tile_shape(M: int, cin: int, cout: int, k: int, dtype: torch.dtype = to
 
 def conv_kernel_name(x: "View", y: "View", cin: int, cout: int, k: int, stride: int, *, residual: bool = False,
                      upsample2x: bool = False) -> str:
-    """Name (as a profiler shows it) of the kernel instance yolo_conv2d_fwd launches for this convolution."""
-    up = 2 if upsample2x else 1
-    M = x.N * (y.H // up) * (y.W // up)
-    tc, tp = conv_tile_shape(M, cin, cout, k, x.buf.dtype)
-    dt = "bf16" if x.buf.dtype == torch.bfloat16 else "float"
-    if tc == 32:
-        return f"conv_igemm_kernel<{dt},32,128,1,4,{'true' if cin == 32 and k == 3 else 'false'}>"
-    return f"conv_igemm_kernel<{dt},{tc},{tp},2,2,{'true' if cin == 32 and k == 3 else 'false'}>"
+    """Short name of the kernel instance yolo_conv2d_fwd launches for this convolution (tile and form)."""
+    buf = ctypes.create_string_buffer(128)
+    xv, yv = x.c(), y.c()
+    check(lib().yolo_conv_kernel_name(ctypes.byref(xv), ctypes.byref(yv), x.N, cin, cout, k, stride, int(upsample2x),
+                                      dtype_code(x.buf.dtype), buf, 128), "yolo_conv_kernel_name")
+    return buf.value.decode()
 
 
 def conv_bnsums_rows(M: int, cin: int, cout: int, k: int, dtype: torch.dtype) -> int:
