@@ -190,8 +190,10 @@ int yolo_decode_noalloc(const yolo_view* head, int L, const int* stride_host, co
  * yolo/modeling/meta_arch/yolo.py:305 (detectron2.layers.batched_nms -> torchvision batched_nms ->
  * torchvision::nms) and the keep[:max_detections] truncation at :307.
  *
- *   boxes/scores/classes  M candidates grouped by image through img_offsets [N+1] (device)
- *   M_host        number of candidates (host value; = img_offsets[N])
+ *   boxes/scores/classes  candidates grouped by image through img_offsets [N+1] (device)
+ *   M_cap         an upper bound of the number of candidates that exist in the arrays (host value, e.g. their
+ *                 capacity); the counts themselves are read on the device from img_offsets, so the host never has to
+ *                 read them back.  Offsets beyond M_cap (a decode that overflowed its capacity) are clamped to it.
  *   iou_thr       suppression when (double)(float iou) > iou_thr, strict
  *   mode          YOLO_NMS_*; AUTO applies torchvision's rule per image with `auto_numel_limit`
  *                 (4000 = what the reference does on CPU, 20000 = on a GPU): coordinate trick when
@@ -203,7 +205,7 @@ int yolo_decode_noalloc(const yolo_view* head, int L, const int* stride_host, co
  *   n_keep        [N] i32 number of valid entries per image
  */
 int yolo_batched_nms(const float* boxes, const float* scores, const int* classes,
-                     const int* img_offsets, int N, int M_host, double iou_thr, int mode,
+                     const int* img_offsets, int N, int M_cap, double iou_thr, int mode,
                      int auto_numel_limit, int top_k, int num_classes, int* keep, int keep_stride,
                      int* n_keep, void* workspace, size_t ws_bytes, void* stream);
 size_t yolo_nms_workspace_bytes(int N, int M);

@@ -134,6 +134,79 @@ def test_nms_stress_608(cuda):
         assert torch.equal(g[:100], t)
 
 
+def test_nms_stress_608_batch_32(cuda):
+    """The NMS stress configuration at its full size: 32 images x 22743 candidates, 80 classes, IoU 0.5, every image
+    against the oracle (all kept indices), and the top-100 form the model uses."""
+    per_image = [util.stress_boxes(22743, 100 + i) for i in range(32)]
+    got = _run_nms(cuda, per_image, 0.5, 0)
+    top = _run_nms(cuda, per_image, 0.5, 0, top_k=100)
+    for p, g, t in zip(per_image, got, top):
+        assert torch.equal(g, _oracle(p, 0.5, 0))
+        assert torch.equal(g[:100], t)
+
+
+def test_nms_counts_come_from_the_device(cuda):
+    """The host passes only an upper bound of the candidate count: arrays larger than the candidates they hold (the
+    tail uninitialised), and offsets beyond the capacity (a decode that overflowed) clamped to it."""
+    from yolo_amd import ops
+    per_image = [util.stress_boxes(n, 300 + i, num_classes=20) for i, n in enumerate([700, 0, 1300, 9000])]
+    want = [_oracle(p, 0.5, 0) for p in per_image]
+    boxes = torch.cat([p[0] for p in per_image])
+    scores = torch.cat([p[1] for p in per_image])
+    classes = torch.cat([p[2] for p in per_image]).to(torch.int32)
+    M = boxes.shape[0]
+    cap = M + 5000
+    pad = lambda t, v: torch.cat([t, torch.full((cap - M,) + tuple(t.shape[1:]), v, dtype=t.dtype)]).to(cuda)
+    offs = torch.tensor([0, 700, 700, 2000, 11000], dtype=torch.int32, device=cuda)
+    keep, n_keep = ops.batched_nms(pad(boxes, float("nan")), pad(scores, 9.0), pad(classes, 3), offs, cap, 0.5,
+                                   num_classes=20, keep_stride=9000)
+    torch.cuda.synchronize()
+    for i, w in enumerate(want):
+        assert torch.equal(keep[i, :int(n_keep[i])].cpu().long(), w)
+    # overflow: the last image claims 9000 candidates but only the first 4000 of them exist
+    cap2 = 2000 + 4000
+    keep, n_keep = ops.batched_nms(boxes[:cap2].to(cuda), scores[:cap2].to(cuda), classes[:cap2].to(cuda), offs, cap2, 0.5,
+                                   num_classes=20, keep_stride=9000)
+    torch.cuda.synchronize()
+    b, s, c = per_image[3]
+    assert torch.equal(keep[3, :int(n_keep[3])].cpu().long(), _oracle((b[:4000], s[:4000], c[:4000]), 0.5, 0))
+    assert torch.equal(keep[2, :int(n_keep[2])].cpu().long(), want[2])
+
+
+def test_nms_coordinate_trick_with_negative_corners(cuda):
+    """torchvision's coordinate trick shifts every class by max_coordinate + 1; a box with negative corners then
+    reaches into the square of the class before it and CAN be suppressed by (or suppress) a box of that class when
+    the IoU threshold is low.  Reproduced exactly: images where that is possible are swept class-agnostically."""
+    from yolo_amd import ops
+    g = torch.Generator().manual_seed(77)
+    n = 400
+    # filler inside [0, 390]^2, three classes
+    c = torch.rand(n, 2, generator=g) * 300 + 40
+    wh = 10 + torch.rand(n, 2, generator=g) * 60
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 390)
+    scores = torch.rand(n, generator=g) * 0.8
+    classes = torch.randint(0, 3, (n,), generator=g)
+    # the largest coordinate is 400 (class 0, high score); class-1 boxes hanging over the top-left corner land, after the
+    # shift by 401, on top of it: [341, 461]^2 against [300, 400]^2 has IoU 0.166
+    boxes = torch.cat([boxes, torch.tensor([[300., 300, 400, 400], [-60., -60, 60, 60], [-50., -70, 65, 55]])])
+    scores = torch.cat([scores, torch.tensor([0.99, 0.9, 0.85])])
+    classes = torch.cat([classes, torch.tensor([0, 1, 1])])
+    case = (boxes, scores, classes)
+    differs = 0
+    for thr in (0.05, 0.1, 0.3):
+        got = _run_nms(cuda, [case], thr, ops.NMS_COORD_TRICK, num_classes=3)[0]
+        ref = _oracle(case, thr, ops.NMS_COORD_TRICK)
+        assert torch.equal(got, ref), thr
+        differs += int(not torch.equal(ref, _oracle(case, thr, ops.NMS_PER_CLASS)))
+    assert differs > 0, "the case does not exercise cross-class suppression"
+    # boxes whose centres are inside the frame and a threshold of 0.25 or more: per-class segments are exact
+    inside = boxes + 70.0
+    shifted = torch.cat([inside[:, :2] - 45.0, inside[:, 2:]], 1)  # negative corners, centres still positive
+    assert float(shifted.min()) < 0 and float((shifted[:, :2] + shifted[:, 2:]).min()) > 0
+    got = _run_nms(cuda, [(shifted, scores, classes)], 0.3, ops.NMS_COORD_TRICK, num_classes=3)[0]
+    assert torch.equal(got, _oracle((shifted, scores, classes), 0.3, ops.NMS_COORD_TRICK))
+
+
 def test_nms_clustered_deep_chains(cuda):
     per_image = [util.clustered_boxes(300, 76, 7 + i) for i in range(2)]
     for mode in (0, 1):

@@ -4,23 +4,31 @@
 // (detectron2.layers.batched_nms -> torchvision.ops.boxes.batched_nms -> torchvision::nms), the
 // keep[:100] truncation at :307 and detectron2's detector_postprocess, for all images of a batch.
 //
-// Pipeline (all on the caller's stream, no host synchronisation):
-//   1. order B: stable radix sort of all candidates by (image, score descending); ties keep index
-//      order.  This is the order torchvision returns kept indices in.
-//   2. order A: stable radix sort of order B by (image, class): per (image, class) segment the boxes
-//      are in descending-score order.
-//   3. one wave per segment runs the greedy sweep in chunks of 64 boxes: lane = box; a chunk is
-//      first tested against the boxes already kept (kept list in LDS, spilling to global memory),
-//      then resolved internally with wave ballots + lane broadcasts.  IoU arithmetic is fp32 in
-//      torchvision's operation order; the file is built with -ffp-contract=off.
-//   4. one workgroup per image walks order B, ranks the kept flags and emits the first top_k.
-// The coordinate-trick branch of torchvision (boxes shifted by class * (max_coordinate + 1) before a
-// single class-agnostic NMS) is reproduced by applying the same fp32 shift to the boxes of each
-// segment: shifted boxes of different classes never overlap, so per-segment sweeps give the same
-// kept set whenever all coordinates are finite.
+// Pipeline (all on the caller's stream; the candidate counts are read ON THE DEVICE from img_offsets, the host only
+// passes an upper bound, so nothing is read back and nothing synchronises):
+//   1. sort kernel, one workgroup per image: a stable radix sort (8-bit digits, counting-sort passes whose ranks come
+//      from wave ballots) of the image's candidates by descending score -- "order B", the order torchvision returns
+//      kept indices in (ties: ascending index) -- then a stable radix sort of order B by class -- "order A", where
+//      every (image, class) segment lists its boxes in descending-score order.  Passes whose digit is the same for
+//      every key are skipped.  The same kernel lists the segment starts, takes the image's largest coordinate
+//      (coordinate trick) and clears the kept flags.
+//   2. sweep kernel, one wave per segment: greedy sweep in chunks of 64 boxes (lane = box); a chunk is first tested
+//      against the boxes already kept (kept list in LDS, spilling to global memory), then resolved internally with
+//      wave ballots + lane broadcasts.  IoU arithmetic is fp32 in torchvision's operation order; the file is built
+//      with -ffp-contract=off.
+//   3. emit kernel, one workgroup per image: walks order B, ranks the kept flags and emits the first top_k.
+//
+// The coordinate-trick branch of torchvision (boxes shifted by class * (max_coordinate + 1) before a single
+// class-agnostic NMS) is reproduced by applying the same fp32 shift to the boxes of each (image, class) segment.
+// Per-segment sweeps equal the class-agnostic sweep as long as shifted boxes of different classes cannot suppress
+// each other.  They cannot when no coordinate of the image is negative (the shifted classes occupy disjoint squares);
+// and with negative corners they cannot when every box centre is non-negative and iou_thr >= 0.25: the overlap of a
+// class-c box with a class-(c-1) box lies in the part of the former left of AND above its class origin, less than a
+// quarter of its area, so the IoU stays below 0.25.  (The decode kernel's boxes always have their centres inside the
+// frame.)  An image that meets neither condition is swept as ONE segment in score order with per-box shifts: the
+// class-agnostic sweep itself, exact but slower.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
+#include <mutex>
 
 #include "common.h"
 
@@ -31,85 +39,373 @@ struct NmsParams {
     const float* scores;
     const int* classes;
     const int* img_offsets;
-    int N, M;
+    int N, cap;  // cap: candidates that exist in the arrays (img_offsets beyond it are clamped)
     double iou_thr;
     int mode, auto_limit, top_k, cbits;
-    unsigned long long* keyB_in;
-    unsigned long long* keyB_out;
-    unsigned* valB_in;
-    unsigned* valB_out;  // order B: original index
-    unsigned* keyA_in;
-    unsigned* keyA_out;  // (image << cbits) | class in order A
-    unsigned* valA_in;
-    unsigned* valA_out;  // order A: position in order B
-    unsigned* seg_start;
+    unsigned *sort_k0, *sort_k1, *sort_v0, *sort_v1;  // [cap] each: (key, value) pairs of the radix passes, ping-pong
+    unsigned* valB;            // [cap] order B: original index
+    unsigned* keyA;            // [cap] (image << cbits) | class in order A
+    unsigned* valA;            // [cap] order A: position in order B
+    unsigned* seg_start;       // [cap]
     unsigned* nseg;
-    float* img_max;
-    unsigned char* keepB;  // kept flag by position in order B
-    f32x4* kept_spill;     // [M] kept boxes beyond the LDS list, addressed by segment start
+    float* img_max;            // [N]
+    unsigned char* agnostic;   // [N] image swept as one class-agnostic segment
+    unsigned char* keepB;      // [cap] kept flag by position in order B
+    f32x4* kept_spill;         // [cap] kept boxes beyond the LDS list, addressed by segment start
     int* keep;
     int keep_stride;
     int* n_keep;
 };
 
-__device__ __forceinline__ int image_of(const int* off, int N, int i) {
-    int lo = 0, hi = N;  // largest n with off[n] <= i
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (off[mid] <= i) lo = mid; else hi = mid;
-    }
-    return lo;
+__device__ __forceinline__ int img_begin(const NmsParams& p, int n) {
+    const int b = p.img_offsets[n];
+    return b < p.cap ? b : p.cap;
 }
 
-__global__ void __launch_bounds__(256) nms_keysB_kernel(const NmsParams p) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.M; i += gridDim.x * 256) {
-        const int n = image_of(p.img_offsets, p.N, i);
-        unsigned u = __float_as_uint(p.scores[i]);
-        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-orderable
-        u = ~u;                                          // descending score = ascending key
-        p.keyB_in[i] = ((unsigned long long)n << 32) | u;
-        p.valB_in[i] = (unsigned)i;
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int RADIX_BITS = 8, RADIX_BINS = 1 << RADIX_BITS;
+
+constexpr int SORT_E = 4;                          // pairs per thread and tile
+constexpr int SORT_TILE = SORT_E * SORT_THREADS;   // 4096 pairs: sub-tile e holds pairs tile + e * 1024 + thread
+
+struct SortShared {
+    unsigned hist[4][RADIX_BINS];                   // digit histograms of up to four passes, taken in one sweep
+    unsigned base[RADIX_BINS];                      // the running output position of every digit
+    unsigned tile_total[RADIX_BINS];                // keys of every digit in the current tile
+    // per (sub-tile, wave), per digit: count in the tile -> exclusive prefix in (sub-tile, wave) order
+    unsigned short wave_count[SORT_E * SORT_WAVES][RADIX_BINS];
+    unsigned tile_first[RADIX_BINS];                // position of every digit's first pair inside the reordered tile
+    unsigned digit_wave_sum[RADIX_BINS / 64];       // (per 64 digits; tile_first is relative to its group of 64)
+    unsigned tile_k[SORT_TILE], tile_v[SORT_TILE];  // the tile reordered by digit, so that runs leave as contiguous stores
+    int uniform_digit;                              // every key has the same digit: the pass moves nothing
+};
+
+// One stable counting-sort pass of m (key, value) pairs on digit `pass` (bits 8 * pass ..) by ONE workgroup, from the
+// digit's histogram in sh.hist[pass]: exclusive scan, then tile after tile (4096 consecutive pairs as four sub-tiles of 1024, one pair per thread and
+// sub-tile, all loaded up front) every pair goes to
+//   base[digit] + (pairs of that digit in lower (sub-tile, wave) groups of the tile) + (... in lower lanes of its wave),
+// the last two from wave ballots -- no atomics decide an order, so equal digits keep their input order.
+// vin == nullptr: the values are the input positions.  Returns false (and moves nothing) when all digits are equal.
+// Histograms of the 8-bit digits at shifts 0, 8, ... (npass of them) of keys[0..m) in one sweep, four loads in flight
+// per thread (a workgroup on its own is bound by load latency, not by bytes).
+__device__ void radix_histograms(const unsigned* keys, int m, int npass, SortShared& sh) {
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 4 * RADIX_BINS; t += SORT_THREADS) (&sh.hist[0][0])[t] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < m; i0 += SORT_TILE) {
+        unsigned k[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int i = i0 + e * SORT_THREADS + tid;
+            k[e] = keys[i < m ? i : m - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e)
+            if (i0 + e * SORT_THREADS + tid < m)
+                for (int ps = 0; ps < npass; ++ps) atomicAdd(&sh.hist[ps][(k[e] >> (ps * RADIX_BITS)) & (RADIX_BINS - 1)], 1u);
     }
+    __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) nms_keysA_kernel(const NmsParams p) {
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < p.M; j += gridDim.x * 256) {
-        const unsigned n = (unsigned)(p.keyB_out[j] >> 32);
-        const unsigned c = (unsigned)p.classes[p.valB_out[j]];
-        p.keyA_in[j] = (n << p.cbits) | c;
-        p.valA_in[j] = (unsigned)j;
+__device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, int m, int pass,
+                           SortShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int shift = pass * RADIX_BITS;
+    if (tid == 0) sh.uniform_digit = 0;
+    __syncthreads();
+    if (tid < RADIX_BINS && sh.hist[pass][tid] == (unsigned)m) sh.uniform_digit = 1;
+    __syncthreads();
+    if (sh.uniform_digit) return false;
+    // exclusive scan of the 256 counts (4 waves)
+    unsigned mine = 0, incl = 0;
+    if (tid < RADIX_BINS) {
+        mine = sh.hist[pass][tid];
+        incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) sh.tile_total[wave] = incl;  // (scratch use: wave sums)
     }
+    __syncthreads();
+    if (tid < RADIX_BINS) {
+        unsigned pre = 0;
+        for (int w = 0; w < wave; ++w) pre += sh.tile_total[w];
+        sh.base[tid] = pre + incl - mine;
+    }
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // Inside the loop the barriers order LDS traffic only (raw s_barrier behind a wait for the LDS counter): a
+    // __syncthreads() would also wait for every global store of the tile before, and for the next tile's loads, which
+    // are requested a whole tile ahead.  Global data is only handed over between passes (the barrier at the end).
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    unsigned kn[SORT_E], vn[SORT_E];
+    auto request = [&](int t0) {  // all loads of a tile in flight together
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int i = t0 + e * SORT_THREADS + tid;
+            const int ic = i < m ? i : m - 1;
+            kn[e] = kin[ic];
+            vn[e] = vin ? vin[ic] : (unsigned)ic;
+        }
+    };
+    request(0);
+    for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
+        unsigned k[SORT_E], v[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            k[e] = kn[e];
+            v[e] = vn[e];
+        }
+        lds_barrier();  // base[] is final for this tile; the last tile's wave_count reads are done
+        {
+            unsigned* z = (unsigned*)&sh.wave_count[0][0];  // SORT_E * 16 * 256 u16 = SORT_E * 2048 u32
+#pragma unroll
+            for (int e = 0; e < 2 * SORT_E; ++e) z[tid + e * SORT_THREADS] = 0;
+        }
+        lds_barrier();
+        int rank[SORT_E];
+        unsigned dg[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const bool valid = t0 + e * SORT_THREADS + tid < m;
+            const unsigned d = (k[e] >> shift) & (RADIX_BINS - 1);
+            dg[e] = d;
+            unsigned long long same = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < RADIX_BITS; ++bit) {
+                const bool set = (d >> bit) & 1u;
+                const unsigned long long bal = __ballot(set);
+                same &= set ? bal : ~bal;
+            }
+            rank[e] = valid ? __popcll(same & lt) : -1;
+            if (valid && rank[e] == 0) sh.wave_count[e * SORT_WAVES + wave][d] = (unsigned short)__popcll(same);
+        }
+        lds_barrier();
+        if (tid < RADIX_BINS) {
+            // all counts of the digit into registers first: reads and writes of one array in one loop would be kept
+            // in order by the compiler, one LDS round trip per group
+            unsigned short c[SORT_E * SORT_WAVES];
+#pragma unroll
+            for (int w = 0; w < SORT_E * SORT_WAVES; ++w) c[w] = sh.wave_count[w][tid];
+            unsigned run = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_E * SORT_WAVES; ++w) {
+                sh.wave_count[w][tid] = (unsigned short)run;
+                run += c[w];
+            }
+            sh.tile_total[tid] = run;
+            // exclusive scan of the tile's digit counts: where each digit's run starts inside the reordered tile
+            unsigned inc = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            sh.tile_first[tid] = inc - run;  // within this wave of 64 digits; the wave sums are added below
+            if (lane == 63) sh.digit_wave_sum[wave] = inc;
+        }
+        lds_barrier();
+        if (t0 + SORT_TILE < m) request(t0 + SORT_TILE);
+        // scatter into the reordered tile (LDS), then write the tile out run by run: consecutive lanes store
+        // consecutive addresses inside a run instead of 64 unrelated words
+        unsigned wave_pre[4];
+        wave_pre[0] = 0;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) wave_pre[w] = wave_pre[w - 1] + sh.digit_wave_sum[w - 1];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            if (rank[e] >= 0) {
+                const unsigned d = dg[e];
+                const unsigned lp = wave_pre[d >> 6] + sh.tile_first[d] + sh.wave_count[e * SORT_WAVES + wave][d] + (unsigned)rank[e];
+                sh.tile_k[lp] = k[e];
+                sh.tile_v[lp] = v[e];
+            }
+        }
+        lds_barrier();
+        const int in_tile = m - t0 < SORT_TILE ? m - t0 : SORT_TILE;
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int j = e * SORT_THREADS + tid;
+            if (j < in_tile) {
+                const unsigned kk = sh.tile_k[j];
+                const unsigned d = (kk >> shift) & (RADIX_BINS - 1);
+                const unsigned pos = sh.base[d] + ((unsigned)j - (wave_pre[d >> 6] + sh.tile_first[d]));
+                kout[pos] = kk;
+                vout[pos] = sh.tile_v[j];
+            }
+        }
+        lds_barrier();
+        if (tid < RADIX_BINS) sh.base[tid] += sh.tile_total[tid];
+    }
+    __syncthreads();  // this workgroup's global stores are visible to its own later loads
+    return true;
 }
 
-__global__ void __launch_bounds__(256) nms_heads_kernel(const NmsParams p) {
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < p.M; t += gridDim.x * 256) {
-        if (t == 0 || p.keyA_out[t] != p.keyA_out[t - 1]) {
-            const unsigned s = atomicAdd(p.nseg, 1u);
-            p.seg_start[s] = (unsigned)t;
+__global__ void __launch_bounds__(SORT_THREADS) nms_sort_kernel(const NmsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    SortShared& sh = *reinterpret_cast<SortShared*>(sort_lds);
+    __shared__ float red_max[SORT_WAVES], red_min[SORT_WAVES], red_cmin[SORT_WAVES];
+    __shared__ unsigned seg_count, seg_base, seg_next;
+    __shared__ int agnostic_s;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = img_begin(p, n), e = img_begin(p, n + 1);
+    const int m = e - b;
+    if (m <= 0) return;
+    // ---- image statistics for the coordinate trick: max / min coordinate, min centre coordinate
+    const bool trick = p.mode == YOLO_NMS_COORD_TRICK || (p.mode == YOLO_NMS_AUTO && 4ll * m <= p.auto_limit);
+    if (trick) {
+        float mx = -INFINITY, mn = INFINITY, cmn = INFINITY;
+        for (int i = tid; i < m; i += SORT_THREADS) {
+            const f32x4 bx = *(const f32x4*)(p.boxes + 4ll * (b + i));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mx = bx[k] > mx ? bx[k] : mx;  // NaNs are ignored by the comparison, as by torch's max()
+                mn = bx[k] < mn ? bx[k] : mn;
+            }
+            const float cx = bx[0] + bx[2], cy = bx[1] + bx[3];  // twice the centre
+            cmn = cx < cmn ? cx : cmn;
+            cmn = cy < cmn ? cy : cmn;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float o = __shfl_down(mx, d, 64), q = __shfl_down(mn, d, 64), r = __shfl_down(cmn, d, 64);
+            mx = o > mx ? o : mx;
+            mn = q < mn ? q : mn;
+            cmn = r < cmn ? r : cmn;
+        }
+        if (lane == 0) {
+            red_max[wave] = mx;
+            red_min[wave] = mn;
+            red_cmin[wave] = cmn;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < SORT_WAVES; ++k) {
+                mx = red_max[k] > mx ? red_max[k] : mx;
+                mn = red_min[k] < mn ? red_min[k] : mn;
+                cmn = red_cmin[k] < cmn ? red_cmin[k] : cmn;
+            }
+            p.img_max[n] = mx;
+            // per-class segments are exact unless a negative corner could reach into the class before (see the top)
+            agnostic_s = !(mn >= 0.0f || (cmn >= 0.0f && p.iou_thr >= 0.25));
+            p.agnostic[n] = (unsigned char)agnostic_s;
+        }
+    } else if (tid == 0) {
+        agnostic_s = 0;
+        p.agnostic[n] = 0;
+    }
+    if (tid == 0) seg_count = seg_next = 0;
+    // ---- order B: stable sort by descending score (= by ascending index among equal scores)
+    unsigned* kbuf[2] = {p.sort_k0 + b, p.sort_k1 + b};
+    unsigned* vbuf[2] = {p.sort_v0 + b, p.sort_v1 + b};
+    for (int i0 = 0; i0 < m; i0 += SORT_TILE) {
+        float sc[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int i = i0 + e * SORT_THREADS + tid;
+            sc[e] = p.scores[b + (i < m ? i : m - 1)];
+        }
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int i = i0 + e * SORT_THREADS + tid;
+            if (i < m) {
+                unsigned u = __float_as_uint(sc[e]);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-orderable
+                kbuf[0][i] = ~u;                                  // descending score = ascending key
+                p.keepB[b + i] = 0;
+            }
         }
     }
-}
-
-// boxes.max() per image, for the coordinate trick (NaNs are ignored by the comparison).
-__global__ void __launch_bounds__(256) nms_imgmax_kernel(const NmsParams p) {
-    __shared__ float red[4];
-    const int n = blockIdx.x;
-    const int b = p.img_offsets[n], e = p.img_offsets[n + 1];
-    float m = -INFINITY;
-    for (int i = 4 * b + threadIdx.x; i < 4 * e; i += 256) {
-        const float v = p.boxes[i];
-        m = v > m ? v : m;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const float o = __shfl_down(m, d, 64);
-        m = o > m ? o : m;
-    }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) m = red[k] > m ? red[k] : m;
-        p.img_max[n] = m;
+    radix_histograms(kbuf[0], m, 4, sh);
+    int cur = 0;
+    bool have_vals = false;  // until a pass has moved something, the values are the positions themselves
+    for (int pass = 0; pass < 4; ++pass) {
+        if (radix_pass(kbuf[cur], have_vals ? vbuf[cur] : nullptr, kbuf[cur ^ 1], vbuf[cur ^ 1], m, pass, sh)) {
+            cur ^= 1;
+            have_vals = true;
+        }
+    }
+    // ---- order A: stable sort of order B by class; a class-agnostic image stays one segment
+    const bool agn = agnostic_s != 0;
+    const int nxt = cur ^ 1;
+    for (int j0 = 0; j0 < m; j0 += SORT_TILE) {
+        unsigned orig[SORT_E], cl[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int j = j0 + e * SORT_THREADS + tid;
+            const int jc = j < m ? j : m - 1;
+            orig[e] = (unsigned)b + (have_vals ? vbuf[cur][jc] : (unsigned)jc);
+        }
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) cl[e] = agn ? 0u : (unsigned)p.classes[orig[e]];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int j = j0 + e * SORT_THREADS + tid;
+            if (j < m) {
+                p.valB[b + j] = orig[e];
+                kbuf[nxt][j] = cl[e];
+            }
+        }
+    }
+    __syncthreads();
+    cur = nxt;
+    have_vals = false;
+    const int cpasses = (p.cbits + RADIX_BITS - 1) / RADIX_BITS;  // <= 2 (at most 65536 classes)
+    radix_histograms(kbuf[cur], m, cpasses, sh);
+    for (int pass = 0; pass < cpasses; ++pass) {
+        if (radix_pass(kbuf[cur], have_vals ? vbuf[cur] : nullptr, kbuf[cur ^ 1], vbuf[cur ^ 1], m, pass, sh)) {
+            cur ^= 1;
+            have_vals = true;
+        }
+    }
+    // ---- segment keys / positions, segment starts
+    const unsigned* ck = kbuf[cur];
+    const unsigned nkey = (unsigned)n << p.cbits;
+    unsigned heads = 0;
+    for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
+        unsigned c[SORT_E], cp[SORT_E], pb[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int t = t0 + e * SORT_THREADS + tid;
+            const int tc = t < m ? t : m - 1;
+            c[e] = ck[tc];
+            cp[e] = tc > 0 ? ck[tc - 1] : ~0u;
+            pb[e] = have_vals ? vbuf[cur][tc] : (unsigned)tc;
+        }
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int t = t0 + e * SORT_THREADS + tid;
+            if (t < m) {
+                p.keyA[b + t] = nkey | c[e];
+                p.valA[b + t] = (unsigned)b + pb[e];
+                heads += cp[e] != c[e] ? 1u : 0u;
+            }
+        }
+    }
+    if (heads) atomicAdd(&seg_count, heads);
+    __syncthreads();
+    if (tid == 0) seg_base = atomicAdd(p.nseg, seg_count);
+    __syncthreads();
+    for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
+        unsigned c[SORT_E], cp[SORT_E];
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int t = t0 + e * SORT_THREADS + tid;
+            const int tc = t < m ? t : m - 1;
+            c[e] = ck[tc];
+            cp[e] = tc > 0 ? ck[tc - 1] : ~0u;
+        }
+#pragma unroll
+        for (int e = 0; e < SORT_E; ++e) {
+            const int t = t0 + e * SORT_THREADS + tid;
+            if (t < m && cp[e] != c[e]) p.seg_start[seg_base + atomicAdd(&seg_next, 1u)] = (unsigned)(b + t);
+        }
     }
 }
 
@@ -148,27 +444,32 @@ __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
     f32x4* klds = kept_lds[wave];
     for (unsigned seg = blockIdx.x * 4 + wave; seg < nseg; seg += gridDim.x * 4) {
         const unsigned start = p.seg_start[seg];
-        const unsigned key = p.keyA_out[start];
+        const unsigned key = p.keyA[start];
         const int n = (int)(key >> p.cbits);
         const unsigned cls = key & cmask;
-        const int m_img = p.img_offsets[n + 1] - p.img_offsets[n];
-        const bool trick = p.mode == YOLO_NMS_COORD_TRICK || (p.mode == YOLO_NMS_AUTO && 4 * m_img <= p.auto_limit);
+        const unsigned img_end = (unsigned)img_begin(p, n + 1);
+        const int m_img = (int)img_end - img_begin(p, n);
+        const bool trick = p.mode == YOLO_NMS_COORD_TRICK || (p.mode == YOLO_NMS_AUTO && 4ll * m_img <= p.auto_limit);
+        const bool agn = p.agnostic[n] != 0;  // the whole image is this one segment; every box shifts by its own class
         // torchvision: offsets = idxs.to(boxes) * (max_coordinate + 1); boxes_for_nms = boxes + offsets
-        const float shift = trick ? (float)cls * (p.img_max[n] + 1.0f) : 0.0f;
+        const float unit = p.img_max[n] + 1.0f;
+        float shift = trick ? (float)cls * unit : 0.0f;
         f32x4* kspill = p.kept_spill + start;
         int nkept = 0;
         const int kcap = p.top_k > 0 ? p.top_k : 0x7fffffff;
-        for (unsigned cs = start; cs < (unsigned)p.M && nkept < kcap; cs += 64) {
+        for (unsigned cs = start; cs < img_end && nkept < kcap; cs += 64) {
             const unsigned t = cs + lane;
-            bool valid = t < (unsigned)p.M;
-            if (valid) valid = p.keyA_out[t] == key;
+            bool valid = t < img_end;
+            if (valid) valid = p.keyA[t] == key;
             const unsigned long long vmask = __ballot(valid);
             if (vmask == 0) break;
             unsigned posB = 0;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (valid) {
-                posB = p.valA_out[t];
-                b = *(const f32x4*)(p.boxes + 4ull * p.valB_out[posB]);
+                posB = p.valA[t];
+                const unsigned orig = p.valB[posB];
+                b = *(const f32x4*)(p.boxes + 4ull * orig);
+                if (agn) shift = (float)p.classes[orig] * unit;
                 if (trick) {
                     b[0] = b[0] + shift;
                     b[1] = b[1] + shift;
@@ -219,14 +520,14 @@ __global__ void __launch_bounds__(256) nms_emit_kernel(const NmsParams p) {
     __shared__ int wsum[4];
     __shared__ int carry_s;
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = p.img_offsets[n], e = p.img_offsets[n + 1];
+    const int b = img_begin(p, n), e = img_begin(p, n + 1);
     const int limit = p.top_k > 0 ? (p.top_k < p.keep_stride ? p.top_k : p.keep_stride) : p.keep_stride;
     int* out = p.keep + (long long)n * p.keep_stride;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = b; base < e; base += 256) {
         const int j = base + tid;
-        const int v = (j < e && j < p.M) ? (int)p.keepB[j] : 0;
+        const int v = j < e ? (int)p.keepB[j] : 0;
         int incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -238,7 +539,7 @@ __global__ void __launch_bounds__(256) nms_emit_kernel(const NmsParams p) {
         int pre = carry_s;
         for (int k = 0; k < wave; ++k) pre += wsum[k];
         const int rank = pre + incl - v;
-        if (v && rank < limit) out[rank] = (int)p.valB_out[j] - b;
+        if (v && rank < limit) out[rank] = (int)p.valB[j] - b;
         __syncthreads();
         if (tid == 255) carry_s = pre + incl;
         __syncthreads();
@@ -315,41 +616,31 @@ __global__ void __launch_bounds__(64) gather_kernel(const GatherParams p) {
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 struct NmsLayout {
-    size_t keyB_in, keyB_out, valB_in, valB_out, keyA_in, keyA_out, valA_in, valA_out, seg_start, nseg, img_max, keepB,
-        kept_spill, sort_tmp, sort_tmp_bytes, total;
+    size_t k0, k1, v0, v1, valB, keyA, valA, seg_start, nseg, img_max, agnostic, keepB, kept_spill, total;
 };
 
-static int nms_layout(int N, int M, NmsLayout& L) {
+static void nms_layout(int N, int cap, NmsLayout& L) {
     size_t o = 0;
-    const size_t m = (size_t)(M > 0 ? M : 1);
+    const size_t m = (size_t)(cap > 0 ? cap : 1);
     auto take = [&](size_t bytes) {
         const size_t r = o;
         o += al(bytes);
         return r;
     };
-    L.keyB_in = take(m * 8);
-    L.keyB_out = take(m * 8);
-    L.valB_in = take(m * 4);
-    L.valB_out = take(m * 4);
-    L.keyA_in = take(m * 4);
-    L.keyA_out = take(m * 4);
-    L.valA_in = take(m * 4);
-    L.valA_out = take(m * 4);
+    L.k0 = take(m * 4);
+    L.k1 = take(m * 4);
+    L.v0 = take(m * 4);
+    L.v1 = take(m * 4);
+    L.valB = take(m * 4);
+    L.keyA = take(m * 4);
+    L.valA = take(m * 4);
     L.seg_start = take(m * 4);
     L.nseg = take(256);
     L.img_max = take((size_t)N * 4);
+    L.agnostic = take((size_t)N);
     L.keepB = take(m);
     L.kept_spill = take(m * 16);
-    size_t t1 = 0, t2 = 0;
-    hipError_t e1 = rocprim::radix_sort_pairs(nullptr, t1, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                              (unsigned*)nullptr, (unsigned*)nullptr, m, 0u, 64u);
-    hipError_t e2 = rocprim::radix_sort_pairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
-                                              (unsigned*)nullptr, m, 0u, 32u);
-    if (e1 != hipSuccess || e2 != hipSuccess) return -1;
-    L.sort_tmp_bytes = t1 > t2 ? t1 : t2;
-    L.sort_tmp = take(L.sort_tmp_bytes);
     L.total = o;
-    return 0;
 }
 
 static int bits_for(unsigned v) {  // bits needed to represent values 0..v-1
@@ -362,32 +653,32 @@ static int bits_for(unsigned v) {  // bits needed to represent values 0..v-1
 
 using namespace yolo;
 
-extern "C" size_t yolo_nms_workspace_bytes(int N, int M) {
-    if (N <= 0 || M < 0) return 0;
+extern "C" size_t yolo_nms_workspace_bytes(int N, int M_cap) {
+    if (N <= 0 || M_cap < 0) return 0;
     NmsLayout L;
-    if (nms_layout(N, M, L) != 0) return 0;
+    nms_layout(N, M_cap, L);
     return L.total;
 }
 
 extern "C" int yolo_batched_nms(const float* boxes, const float* scores, const int* classes, const int* img_offsets,
-                                int N, int M_host, double iou_thr, int mode, int auto_numel_limit, int top_k,
+                                int N, int M_cap, double iou_thr, int mode, int auto_numel_limit, int top_k,
                                 int num_classes, int* keep, int keep_stride, int* n_keep, void* workspace,
                                 size_t ws_bytes, void* stream) {
     YOLO_REQUIRE(img_offsets && keep && n_keep, "nms: null argument");
     YOLO_REQUIRE(N >= 1 && N <= 65535, "nms: batch %d (1..65535)", N);
-    YOLO_REQUIRE(M_host >= 0, "nms: negative candidate count");
+    YOLO_REQUIRE(M_cap >= 0, "nms: negative candidate capacity");
     YOLO_REQUIRE(mode >= YOLO_NMS_PER_CLASS && mode <= YOLO_NMS_AUTO, "nms: mode %d", mode);
     YOLO_REQUIRE(keep_stride > 0 && top_k >= 0, "nms: keep_stride %d / top_k %d", keep_stride, top_k);
     YOLO_REQUIRE(num_classes >= 1 && num_classes <= 65536, "nms: num_classes %d", num_classes);
     hipStream_t st = (hipStream_t)stream;
-    if (M_host == 0) {
+    if (M_cap == 0) {
         hipLaunchKernelGGL(nms_zero_counts_kernel, dim3((N + 255) / 256), dim3(256), 0, st, n_keep, N);
         YOLO_CHECK_HIP(hipGetLastError());
         return YOLO_OK;
     }
     YOLO_REQUIRE(boxes && scores && classes && workspace, "nms: null argument");
     NmsLayout L;
-    if (nms_layout(N, M_host, L) != 0) return fail(YOLO_E_HIP, "nms: rocprim temp-storage query failed");
+    nms_layout(N, M_cap, L);
     if (ws_bytes < L.total) return fail(YOLO_E_WORKSPACE, "nms: workspace %zu < %zu bytes", ws_bytes, L.total);
     const int cbits = bits_for((unsigned)num_classes);
     const int nbits = bits_for((unsigned)N);
@@ -400,46 +691,41 @@ extern "C" int yolo_batched_nms(const float* boxes, const float* scores, const i
     p.classes = classes;
     p.img_offsets = img_offsets;
     p.N = N;
-    p.M = M_host;
+    p.cap = M_cap;
     p.iou_thr = iou_thr;
     p.mode = mode;
     p.auto_limit = auto_numel_limit;
     p.top_k = top_k;
     p.cbits = cbits;
-    p.keyB_in = (unsigned long long*)(ws + L.keyB_in);
-    p.keyB_out = (unsigned long long*)(ws + L.keyB_out);
-    p.valB_in = (unsigned*)(ws + L.valB_in);
-    p.valB_out = (unsigned*)(ws + L.valB_out);
-    p.keyA_in = (unsigned*)(ws + L.keyA_in);
-    p.keyA_out = (unsigned*)(ws + L.keyA_out);
-    p.valA_in = (unsigned*)(ws + L.valA_in);
-    p.valA_out = (unsigned*)(ws + L.valA_out);
+    p.sort_k0 = (unsigned*)(ws + L.k0);
+    p.sort_k1 = (unsigned*)(ws + L.k1);
+    p.sort_v0 = (unsigned*)(ws + L.v0);
+    p.sort_v1 = (unsigned*)(ws + L.v1);
+    p.valB = (unsigned*)(ws + L.valB);
+    p.keyA = (unsigned*)(ws + L.keyA);
+    p.valA = (unsigned*)(ws + L.valA);
     p.seg_start = (unsigned*)(ws + L.seg_start);
     p.nseg = (unsigned*)(ws + L.nseg);
     p.img_max = (float*)(ws + L.img_max);
+    p.agnostic = (unsigned char*)(ws + L.agnostic);
     p.keepB = (unsigned char*)(ws + L.keepB);
     p.kept_spill = (f32x4*)(ws + L.kept_spill);
     p.keep = keep;
     p.keep_stride = keep_stride;
     p.n_keep = n_keep;
 
-    int blocks = (M_host + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    static std::once_flag attr_once;  // the sort kernel's tables and its reordered tile: 70 KiB of dynamic LDS
+    static hipError_t attr_status = hipSuccess;
+    constexpr int SORT_LDS = (int)sizeof(SortShared);
+    std::call_once(attr_once, [&] {
+        attr_status = hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS);
+    });
+    YOLO_CHECK_HIP(attr_status);
     YOLO_CHECK_HIP(hipMemsetAsync(p.nseg, 0, 256, st));
-    YOLO_CHECK_HIP(hipMemsetAsync(p.keepB, 0, al((size_t)M_host), st));
-    hipLaunchKernelGGL(nms_keysB_kernel, dim3(blocks), dim3(256), 0, st, p);
-    size_t tmp = L.sort_tmp_bytes;
-    YOLO_CHECK_HIP(rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, p.keyB_in, p.keyB_out, p.valB_in, p.valB_out,
-                                             (size_t)M_host, 0u, (unsigned)(32 + nbits), st));
-    hipLaunchKernelGGL(nms_keysA_kernel, dim3(blocks), dim3(256), 0, st, p);
-    tmp = L.sort_tmp_bytes;
-    YOLO_CHECK_HIP(rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, p.keyA_in, p.keyA_out, p.valA_in, p.valA_out,
-                                             (size_t)M_host, 0u, (unsigned)(cbits + nbits), st));
-    hipLaunchKernelGGL(nms_heads_kernel, dim3(blocks), dim3(256), 0, st, p);
-    if (mode != YOLO_NMS_PER_CLASS) hipLaunchKernelGGL(nms_imgmax_kernel, dim3(N), dim3(256), 0, st, p);
-    // one wave per segment; at most N*num_classes segments
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(SORT_THREADS), SORT_LDS, st, p);
+    // one wave per segment; at most N * num_classes segments, and no more than candidates
     long long segs = (long long)N * num_classes;
-    if (segs > M_host) segs = M_host;
+    if (segs > M_cap) segs = M_cap;
     long long sblocks = (segs + 3) / 4;
     if (sblocks > 4096) sblocks = 4096;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)sblocks), dim3(256), 0, st, p);

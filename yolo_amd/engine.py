@@ -52,7 +52,7 @@ class Plan:
     nms_ws: Optional[torch.Tensor] = None
     keep: Optional[torch.Tensor] = None
     n_keep: Optional[torch.Tensor] = None
-    total_host: Optional[torch.Tensor] = None  # pinned int32[1]: candidate count read-back
+    cand_cap: int = 0  # capacity wanted for the candidate buffers (0: the default of 4096 per image)
     flops: int = 0  # conv multiply-add FLOPs (2 per MAC) of one forward at this batch
     meta: List[dict] = field(default_factory=list)  # per conv step: name, x, y, slope, residual, up
 
@@ -259,7 +259,7 @@ class Yolov3Engine:
     @ops.on_own_device
     def decode(self, P: Plan, score_thr: float, cap: Optional[int] = None) -> ops.Candidates:
         if cap is None:
-            cap = P.N * 4096
+            cap = max(P.cand_cap, P.N * 4096)
         if P.cand is None or P.cand.scores.numel() < cap:
             dev = self.device
             P.cand = ops.Candidates(torch.empty((cap, 4), dtype=torch.float32, device=dev),
@@ -272,10 +272,9 @@ class Yolov3Engine:
 
     @ops.on_own_device
     def submit(self, images: torch.Tensor, *, score_thr: float, mean, std, padded_hw=None, slot: int = 0) -> "InFlight":
-        """First half of detect(): enqueue backbone + neck + heads + decode for a batch and start the
-        asynchronous read-back of the candidate count.  Nothing here waits for the GPU.  ``slot`` selects one of
-        several independent sets of activation buffers, so that batch i+1 can be submitted before batch i is
-        finished (finish() then overlaps with the GPU work already queued behind it)."""
+        """First half of detect(): enqueue backbone + neck + heads + decode for a batch.  Nothing here waits for the
+        GPU.  ``slot`` selects one of several independent sets of activation buffers, so that batch i+1 can be
+        submitted before batch i is finished (its post-processing then runs next to batch i+1's convolutions)."""
         N, _, Hs, Ws = images.shape
         if padded_hw is None:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
@@ -283,7 +282,7 @@ class Yolov3Engine:
         self.run_backbone(images, mean, std, padded_hw, plan=P)
         # The decode launches (small, latency-bound) go to their own stream behind the batch's last convolution, so
         # the next batch's convolutions follow this batch's directly on the main stream.  The head tensors of this
-        # slot are not written again before finish() has waited for the decode on the host.
+        # slot are not written again before the main stream has waited for this slot's post-processing (finish()).
         main = torch.cuda.current_stream(self.device)
         dstream = self._decode_stream() if self.nms_on_side_stream else main
         if dstream is not main:
@@ -292,9 +291,6 @@ class Yolov3Engine:
             t0 = self._trace_begin()
             cand = self.decode(P, score_thr)
             self._trace_end("decode", t0)
-            if P.total_host is None:
-                P.total_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            P.total_host.copy_(cand.img_offsets[N:N + 1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         return InFlight(P, cand, ev, score_thr, (N, Hs, Ws))
@@ -302,34 +298,30 @@ class Yolov3Engine:
     @ops.on_own_device
     def finish(self, h: "InFlight", *, nms_thr: float, max_det: int = 100, nms_mode: int = ops.NMS_AUTO,
                auto_limit: int = 20000, in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
-        """Second half of detect(): wait for the candidate count of a submitted batch (the one host read-back
-        per batch), then enqueue batched NMS + top-k gather.  Returns (det [N, max_det, 6], n_det [N])."""
+        """Second half of detect(): enqueue batched NMS + top-k gather behind the batch's decode.  The candidate
+        counts stay on the device (the NMS reads them there), so nothing is read back and the host never waits.
+        Returns (det [N, max_det, 6], n_det [N]).  A batch with more candidates than the candidate buffers hold is
+        processed on the first ``capacity`` of them; ``overflowed(h)`` tells (it reads one word back)."""
         P, cand = h.plan, h.cand
-        h.event.synchronize()
-        total = int(P.total_host[0])
         cap = cand.scores.numel()
-        if total > cap:  # rare: grow and decode again (nothing was lost, only not written)
-            P.cand = None
-            cand = self.decode(P, h.score_thr, cap=int(total * 1.25) + 1024)
-            total = int(cand.img_offsets[P.N].item())
         dev = self.device
-        # NMS + gather go to a side stream: a dozen launch-bound kernels that would otherwise sit between two
-        # batches' convolutions on the main stream.  Their inputs are complete (the host has just waited for the
-        # batch's decode); the main stream waits for them before it goes on, which orders both the caller's use of
-        # the result and the next reuse of this slot's candidate buffers -- at that point the main stream is still
-        # busy with the convolutions queued by the following submit(), so the wait costs nothing.
+        # NMS + gather go to a side stream: a few launch-bound kernels that would otherwise sit between two batches'
+        # convolutions on the main stream.  The main stream waits for them before it goes on, which orders both the
+        # caller's use of the result and the next reuse of this slot's buffers -- at that point the main stream is
+        # still busy with the convolutions queued by the following submit(), so the wait costs nothing.
         main = torch.cuda.current_stream(dev)
         side = self._side_stream() if self.nms_on_side_stream else main
+        if side is not main:
+            side.wait_event(h.event)
         with torch.cuda.stream(side):
             t0 = self._trace_begin()
             if P.keep is None or P.keep.shape[1] != max_det:
                 P.keep = torch.empty((P.N, max_det), dtype=torch.int32, device=dev)
                 P.n_keep = torch.empty((P.N,), dtype=torch.int32, device=dev)
-            if total > 0:
-                need = ops.nms_workspace_bytes(P.N, total)
-                if P.nms_ws is None or P.nms_ws.numel() < need:
-                    P.nms_ws = torch.empty(int(need * 1.5), dtype=torch.uint8, device=dev)
-            ops.batched_nms(cand.boxes, cand.scores, cand.classes, cand.img_offsets, total, nms_thr,
+            need = ops.nms_workspace_bytes(P.N, cap)
+            if P.nms_ws is None or P.nms_ws.numel() < need:
+                P.nms_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ops.batched_nms(cand.boxes, cand.scores, cand.classes, cand.img_offsets, cap, nms_thr,
                             num_classes=self.num_classes, mode=nms_mode, auto_limit=auto_limit, top_k=max_det,
                             keep_stride=max_det, workspace=P.nms_ws, keep=P.keep, n_keep=P.n_keep)
             N, Hs, Ws = h.geom
@@ -346,6 +338,20 @@ class Yolov3Engine:
             det.record_stream(main)
             n_det.record_stream(main)
         return det, n_det
+
+    def grow_candidates(self, h: "InFlight") -> bool:
+        """After a batch: if it produced more candidates than its buffers hold, enlarge the plan's buffers (for the
+        next run) and return True -- the caller runs the batch again.  Waits for the batch's decode."""
+        over = self.overflowed(h)
+        if over:
+            h.plan.cand_cap = int((h.cand.scores.numel() + over) * 1.25) + 1024
+        return over > 0
+
+    def overflowed(self, h: "InFlight") -> int:
+        """Candidates the batch produced beyond the capacity of its candidate buffers (0 = none were dropped).
+        Reads one word back from the device, i.e. waits for the batch's decode."""
+        total = int(h.cand.img_offsets[h.plan.N].item())
+        return max(0, total - h.cand.scores.numel())
 
     def _trace_begin(self):
         if self.trace_events is None:
@@ -381,8 +387,10 @@ class Yolov3Engine:
         """Full inference for a batch.  Returns (det [N, max_det, 6], n_det [N]) on the GPU:
         x0,y0,x1,y1 (output frame), score, class."""
         h = self.submit(images, score_thr=score_thr, mean=mean, std=std, padded_hw=padded_hw)
-        return self.finish(h, nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode, auto_limit=auto_limit,
-                           in_hw=in_hw, out_hw=out_hw)
+        out = self.finish(h, nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode, auto_limit=auto_limit,
+                          in_hw=in_hw, out_hw=out_hw)
+        self.last_in_flight = h
+        return out
 
     def detect_pipelined(self, batches, *, score_thr: float, nms_thr: float, mean, std, max_det: int = 100,
                          nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000, depth: int = 2):

@@ -321,10 +321,16 @@ class YOLOV3(nn.Module):
         in_hw = torch.tensor(sizes, dtype=torch.int32, device=dev)
         out = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
         out_hw = torch.tensor(out, dtype=torch.int32, device=dev)
-        det, n_det = self.backbone.engine().detect(
-            batch, score_thr=self.test_score_thresh, nms_thr=self.test_nms_thresh, mean=self._mean, std=self._std,
-            max_det=self.max_detections_pre_image, nms_mode=self.nms_mode, auto_limit=self.nms_auto_numel,
-            in_hw=in_hw, out_hw=out_hw)
+        eng = self.backbone.engine()
+        for _ in range(2):
+            det, n_det = eng.detect(
+                batch, score_thr=self.test_score_thresh, nms_thr=self.test_nms_thresh, mean=self._mean, std=self._std,
+                max_det=self.max_detections_pre_image, nms_mode=self.nms_mode, auto_limit=self.nms_auto_numel,
+                in_hw=in_hw, out_hw=out_hw)
+            # rare (thousands of candidates per image, e.g. a very low threshold): the candidate buffers were too
+            # small and the tail of the candidates was dropped -- run the batch again with larger ones
+            if not eng.grow_candidates(eng.last_in_flight):
+                break
         n_det = n_det.tolist()
         results = []
         for n, (oh, ow) in enumerate(out):

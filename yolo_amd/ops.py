@@ -325,7 +325,9 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, classes: torch.Tensor
                 M: int, iou_thr: float, *, num_classes: int, mode: int = NMS_PER_CLASS, auto_limit: int = 20000,
                 top_k: int = 0, keep_stride: Optional[int] = None, workspace: Optional[torch.Tensor] = None,
                 keep: Optional[torch.Tensor] = None, n_keep: Optional[torch.Tensor] = None):
-    """Returns (keep [N, keep_stride] i32 image-relative indices, n_keep [N] i32)."""
+    """Returns (keep [N, keep_stride] i32 image-relative indices, n_keep [N] i32).  ``M`` is an upper bound of the
+    number of candidates in the arrays (their capacity will do): the counts are read on the device from
+    ``img_offsets``, nothing is read back."""
     _require_cuda(img_offsets, "batched_nms")
     dev = img_offsets.device
     N = img_offsets.numel() - 1
