@@ -105,6 +105,7 @@ def main():
     rows = [nms_case("stress uniform 32 x 22743", [stress(22743, 100 + i) for i in range(32)], reps, 0),
             nms_case("stress uniform 32 x 22743, top-100", [stress(22743, 100 + i) for i in range(32)], reps, 100),
             nms_case("stress clustered 32 x (300 x 76)", [clustered(300, 76, 200 + i) for i in range(32)], reps, 0),
+            nms_case("benchmark-like 64 x 200, top-100", [stress(200, 300 + i, side=416.0) for i in range(64)], reps, 100),
             decode_case(reps, torch.float32), decode_case(reps, torch.bfloat16)]
     for r in rows:
         print(json.dumps(r))

@@ -165,16 +165,21 @@ __device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* k
         {
             unsigned* z = (unsigned*)&sh.wave_count[0][0];  // SORT_E * 16 * 256 u16 = SORT_E * 2048 u32
 #pragma unroll
-            for (int e = 0; e < 2 * SORT_E; ++e) z[tid + e * SORT_THREADS] = 0;
+            for (int e = 0; e < 2 * SORT_E; ++e)
+                if (e < 2 * ((m - t0 + SORT_THREADS - 1) / SORT_THREADS)) z[tid + e * SORT_THREADS] = 0;
         }
         lds_barrier();
         int rank[SORT_E];
         unsigned dg[SORT_E];
+        // sub-tiles in use (wave-uniform): a small image fills only the first one
+        const int ne = (m - t0 + SORT_THREADS - 1) / SORT_THREADS < SORT_E ? (m - t0 + SORT_THREADS - 1) / SORT_THREADS : SORT_E;
 #pragma unroll
         for (int e = 0; e < SORT_E; ++e) {
             const bool valid = t0 + e * SORT_THREADS + tid < m;
             const unsigned d = (k[e] >> shift) & (RADIX_BINS - 1);
             dg[e] = d;
+            rank[e] = -1;
+            if (e >= ne) continue;
             unsigned long long same = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < RADIX_BITS; ++bit) {
@@ -191,11 +196,11 @@ __device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* k
             // in order by the compiler, one LDS round trip per group
             unsigned short c[SORT_E * SORT_WAVES];
 #pragma unroll
-            for (int w = 0; w < SORT_E * SORT_WAVES; ++w) c[w] = sh.wave_count[w][tid];
+            for (int w = 0; w < SORT_E * SORT_WAVES; ++w) c[w] = w < ne * SORT_WAVES ? sh.wave_count[w][tid] : (unsigned short)0;
             unsigned run = 0;
 #pragma unroll
             for (int w = 0; w < SORT_E * SORT_WAVES; ++w) {
-                sh.wave_count[w][tid] = (unsigned short)run;
+                if (w < ne * SORT_WAVES) sh.wave_count[w][tid] = (unsigned short)run;
                 run += c[w];
             }
             sh.tile_total[tid] = run;
