@@ -83,6 +83,20 @@ int yolo_conv_cout_pad(int Cout);
  * yolo_conv2d_fwd uses for M = N*Ho*Wo output pixels and Cout channels, i.e. which kernel instance runs. */
 int yolo_conv_tile_shape(int M, int Cin, int Cout, int k, int dtype, int* tile_channels, int* tile_pixels);
 
+/*
+ * yolo_conv2d_fwd for layers with too few output pixels to occupy the chip (single images: 16-58 workgroup tiles for
+ * 256 CUs): the k loop of every tile is split over several workgroups that write f32 partial sums into `workspace`,
+ * and a second launch adds them in a fixed order, applies bias / LeakyReLU / residual and stores the output view.
+ * Same arguments and results as yolo_conv2d_fwd (sums are associated differently: equal to rounding).  bf16 inputs;
+ * shapes for which splitting does not pay (yolo_conv2d_splitk_plan says splits == 1) run the plain launch.
+ *   yolo_conv2d_splitk_plan: splits and workspace bytes for a convolution with M = N*Ho*Wo output pixels.
+ */
+int yolo_conv2d_splitk_plan(int M, int Cin, int Cout, int k, int stride, int dtype, int* splits, size_t* workspace_bytes);
+int yolo_conv2d_fwd_splitk(const yolo_view* x, const void* w_packed, const float* bias,
+                           const yolo_view* residual, const yolo_view* y,
+                           int N, int Cin, int Cout, int k, int stride, float leaky_slope, int upsample2x,
+                           int dtype, int y_dtype, void* workspace, size_t ws_bytes, void* stream);
+
 /* Introspection for benchmarks and profilers: a short name of the kernel instance yolo_conv2d_fwd launches for this
  * convolution, "conv_igemm_kernel<dtype,tile channels,tile pixels,wave layout,form>" with form = plain | tap2 | strip
  * (strip: the 3x3 / stride-1 form whose three kw taps share one staged strip of pixel rows). */
@@ -214,10 +228,11 @@ size_t yolo_nms_workspace_bytes(int N, int M);
  * Gather kept detections and map them to the output frame.  Replaces pred[keep[:100]] (yolo.py:307)
  * and detectron2's detector_postprocess (scale to the requested size, clip, drop empty boxes).
  *   in_hw  [N][2] i32 (device) network-input image size (h,w) before padding; out_hw [N][2] requested size
+ *   M_cap       the capacity given to yolo_batched_nms (image starts beyond it are clamped to it, as there)
  *   det         [N][keep_stride][6] f32: x0,y0,x1,y1,score,class ; n_det [N] i32
  */
 int yolo_gather_detections(const float* boxes, const float* scores, const int* classes,
-                           const int* img_offsets, const int* keep, int keep_stride, const int* n_keep,
+                           const int* img_offsets, int M_cap, const int* keep, int keep_stride, const int* n_keep,
                            int N, const int* in_hw, const int* out_hw,
                            float* det, int* n_det, void* stream);
 

@@ -307,3 +307,54 @@ def test_resblock_c64_fused(cuda, geom):
     from yolo_amd._lib import YoloHipError
     with pytest.raises(YoloHipError, match="overlap"):
         ops.resblock_c64_fwd(xv, wp1, bp1, wp2, bp2, xv)
+
+
+# (Cin, Cout, k, stride, N, H, W, residual, upsample): few-pixel layers, where the k loop of a tile is split over
+# several workgroups (single-image inference)
+SPLITK_SHAPES = [(512, 1024, 3, 1, 1, 13, 13, True, False), (256, 512, 3, 1, 1, 26, 26, True, False),
+                 (1024, 512, 1, 1, 1, 13, 13, False, False), (128, 256, 3, 1, 1, 52, 52, False, False),
+                 (512, 256, 1, 1, 2, 13, 13, False, True), (1024, 255, 1, 1, 1, 13, 13, False, False),
+                 (256, 512, 3, 2, 1, 52, 52, False, False), (768, 256, 1, 1, 1, 26, 26, False, False)]
+
+
+@pytest.mark.parametrize("shape", SPLITK_SHAPES, ids=lambda s: "x".join(map(str, s[:7])))
+def test_conv_splitk(cuda, shape):
+    """yolo_conv2d_fwd_splitk against the torch reference and against yolo_conv2d_fwd (equal to bf16 rounding)."""
+    from yolo_amd import ops
+    cin, cout, k, stride, N, H, W, use_res, up = shape
+    g = torch.Generator().manual_seed(cin + W)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    is_head = cout == 255
+    norm = None if is_head else _rand_norm(cout, g)
+    bias = 0.5 * torch.randn(cout, generator=g) if is_head else None
+    slope = 1.0 if is_head else 0.1
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(N, cout, Ho, Wo, generator=g) if use_res else None
+    wf, bf = ops.fold_norm(w, bias, norm)
+    ref = _ref_conv(x.bfloat16().float(), wf.bfloat16().float(), None, bf, stride, slope,
+                    res.bfloat16().float() if use_res else None)
+    if up:
+        ref = F.interpolate(ref, scale_factor=2.0, mode="nearest")
+    wp, bp = ops.pack_conv(wf, bf, torch.bfloat16, cuda)
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    ydt = torch.float32 if is_head else torch.bfloat16
+    f = 2 if up else 1
+    outs = []
+    splits, nbytes = ops.conv_splitk_plan(N * Ho * Wo, cin, cout, k, stride, torch.bfloat16)
+    assert splits > 1 and nbytes > 0
+    ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=cuda)  # NaN bit patterns: nothing unwritten is read
+    for split in (True, False):
+        yv = ops.alloc_view(N, Ho * f, Wo * f, (cout + 7) // 8 * 8, 1, ydt, cuda)
+        rv = ops.view_from_nchw(res.to(cuda), 1, torch.bfloat16) if use_res else None
+        if split:
+            ops.conv2d_fwd_splitk(xv, wp, bp, yv, ws, cin=cin, cout=cout, k=k, stride=stride, slope=slope, residual=rv,
+                                  upsample2x=up)
+        else:
+            ops.conv2d_fwd(xv, wp, bp, yv, cin=cin, cout=cout, k=k, stride=stride, slope=slope, residual=rv, upsample2x=up)
+        torch.cuda.synchronize()
+        outs.append(yv.nchw()[:, :cout].float().cpu())
+        assert float(yv.buf[:, 0].abs().max()) == 0.0 and float(yv.buf[:, :, 0].abs().max()) == 0.0
+    assert _rel_err(outs[0], ref) < (1e-3 if is_head else BF16_TOL)
+    assert float((outs[0] - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    assert _rel_err(outs[0], outs[1]) < 2.0 ** -7

@@ -59,6 +59,9 @@ SIGNATURES = {
     "yolo_conv_cout_pad": (c_int, [c_int]),
     "yolo_conv_tile_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, _IP, _IP]),
     "yolo_conv_kernel_name": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
+    "yolo_conv2d_splitk_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _IP, ctypes.POINTER(c_size_t)]),
+    "yolo_conv2d_fwd_splitk": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int,
+                                       c_float, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "yolo_conv2d_fwd": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_int, c_int, c_void_p]),
     "yolo_stem_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p, c_void_p, _VP,
@@ -112,7 +115,7 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
     "yolo_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "yolo_gather_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+    "yolo_gather_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -50,6 +50,8 @@ struct ConvParams {
     int y_f32;  // output element type is f32 (else bf16)
     int Mc;        // S2D kernels: pixels per parity class (N * Hi * Wi); n_ptiles = 4 * tiles per class
     int Wreal;     // STRIP kernels: real output width; p.Wo is then the row length INCLUDING the two halo columns
+    int split_steps;            // split-K launches: k-steps per split (0 = the whole k range in one workgroup)
+    long long y_split_stride;   // split-K launches: bytes between the f32 partial-sum slabs of consecutive splits
     float* stats;  // STATS kernels: per pixel tile, per channel: [n_ptiles][2][Cout] sums of y and y*y
 };
 
@@ -169,6 +171,14 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
         tile_c = logical % p.n_ctiles;
         tile_p = logical / p.n_ctiles;
     }
+    // split-K launch: the grid holds `splits` copies of the tile grid; copy s sums k-steps [s * split_steps, ...) into
+    // its own f32 slab (no bias, no activation: conv_splitk_reduce_kernel finishes the layer)
+    int split = 0;
+    if (p.split_steps) {
+        split = tile_p / p.n_ptiles;
+        tile_p -= split * p.n_ptiles;
+    }
+    char* const ybase = p.y + (long long)split * p.y_split_stride;
     // S2D: parity class of this tile and its pixel range inside the class
     int par_a = 0, par_b = 0, pix_base = tile_p * TP, pix_end = p.M;
     if constexpr (S2D) {
@@ -235,6 +245,13 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 
     // k-step cursor (wave-uniform)
     int cur_cc = 0, cur_kh = 0, cur_kw = 0, cur_step = 0;
+    if (p.split_steps) {  // first k-step of this split -> (tap, channel chunk)
+        cur_step = split * p.split_steps;
+        const int tap = cur_step / p.cpt;
+        cur_cc = cur_step - tap * p.cpt;
+        cur_kh = tap / p.ksize;
+        cur_kw = tap - cur_kh * p.ksize;
+    }
     auto stage = [&](char* buf) {
         int xoff;
         if constexpr (TAP2) {
@@ -294,7 +311,8 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     f32x4 acc[FC][FP];
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
-        const f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + wc * (TC / WC) + q * 4 + i * 16);
+        f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + wc * (TC / WC) + q * 4 + i * 16);
+        if (p.split_steps) bv = f32x4{0.f, 0.f, 0.f, 0.f};  // partial sums: the bias is added once, by the reduction
 #pragma unroll
         for (int j = 0; j < FP; ++j) acc[i][j] = bv;
     }
@@ -372,7 +390,11 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     };
 
     // ---- main loop: loads of step s+1 fly while step s is multiplied
-    const int nsteps = S2D ? (1 + par_a) * (1 + par_b) * p.cpt : p.nsteps;
+    int nsteps = S2D ? (1 + par_a) * (1 + par_b) * p.cpt : p.nsteps;
+    if (p.split_steps) {
+        const int left = p.nsteps - split * p.split_steps;
+        nsteps = left < p.split_steps ? left : p.split_steps;
+    }
     TRACE_MARK(9);
     if constexpr (STRIP) {
         // LDS: two weight buffers, then two strip buffers.  Group g = (kh, cc) runs three k-steps (kw = 0, 1, 2) on one
@@ -585,7 +607,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                             v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
                         }
                     }
-                    char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)oh * p.y_row_stride +
+                    char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)oh * p.y_row_stride +
                                ow * p.y_pix_stride + (size_t)ch_first * (YF ? 4 : 2);
                     [[maybe_unused]] u32x4 packed;
                     if constexpr (YF) {  // f32 output (the head tensors)
@@ -630,7 +652,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                             v1 += *(const f32x4*)(rp + 16);
                         }
                     }
-                    char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(oh * up) * p.y_row_stride +
+                    char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)(oh * up) * p.y_row_stride +
                                (ow * up) * p.y_pix_stride + (size_t)ch_first * (p.y_f32 ? 4 : 2);
                     u32x4 packed;
                     if (!p.y_f32) {
@@ -715,7 +737,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
           bool STRIP = false>
-static int launch_conv(const ConvParams& p, hipStream_t stream) {
+static int launch_conv(const ConvParams& p, hipStream_t stream, int copies = 1) {
     // two operand buffers, or the f32 epilogue staging tile if that is larger (STRIP: two weight buffers + two strips
     // of ceil((TP + 2) / 8) KiB, and the staging tile whole)
     constexpr int OPS = STRIP ? 2 * TC * ROWB + 2 * ((TP + 2 + 7) / 8) * 1024 : 2 * (TC + TP) * ROWB;
@@ -734,7 +756,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
         attr_status = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
     YOLO_CHECK_HIP(attr_status);
-    const int nblocks = p.n_ctiles * p.n_ptiles;
+    const int nblocks = p.n_ctiles * p.n_ptiles * copies;  // copies > 1: split-K (see the kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), LDS, stream, p);
     YOLO_CHECK_HIP(hipGetLastError());
 #ifdef YOLO_CONV_TRACE
@@ -755,6 +777,11 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     }
 #endif
     return YOLO_OK;
+}
+
+template <typename T, int TC, int TP>
+static int launch_conv_copies(const ConvParams& p, int copies, hipStream_t stream) {
+    return launch_conv<T, TC, TP, 2, 2, false>(p, stream, copies);
 }
 
 // Pixel-tile choice (64, 96, 128 or 192).  Two workgroups share a CU (three of the 64-pixel tile, 48 KB of LDS each),
@@ -962,6 +989,214 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
     }
     if (dtype == YOLO_BF16) return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st);
     return dispatch_tc<float, false>(p, tc, st);
+}
+
+namespace yolo {
+
+struct SplitReduceParams {
+    const float* slabs;          // [splits][M][Cp] f32 partial sums
+    long long slab_stride;       // elements
+    const float* bias;
+    const char* res;
+    char* y;
+    long long y_img_stride, y_origin, r_img_stride, r_origin;  // bytes
+    int y_row_stride, y_pix_stride, r_row_stride, r_pix_stride;
+    int M, Ho, Wo, Cout, Cp, splits;
+    float slope;
+    int upsample, y_f32, res_f32;
+};
+
+// Finishes a split-K convolution: sum of the partial-sum slabs + bias -> LeakyReLU -> (+ residual) -> output view
+// (bf16 or f32, 2x upsample, channel slice).  One thread = 8 channels of one pixel.
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const SplitReduceParams p) {
+    const int groups = (p.Cout + 7) / 8;
+    const long long total = (long long)p.M * groups;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int m = (int)(t / groups), g = (int)(t - (long long)m * groups);
+        const int c0 = g * 8;
+        const float* src = p.slabs + (long long)m * p.Cp + c0;
+        f32x4 v0 = *(const f32x4*)(p.bias + c0), v1 = *(const f32x4*)(p.bias + c0 + 4);
+        for (int s = 0; s < p.splits; ++s) {  // fixed order: the result does not depend on the launch's timing
+            v0 += *(const f32x4*)(src + s * p.slab_stride);
+            v1 += *(const f32x4*)(src + s * p.slab_stride + 4);
+        }
+        v0 = leaky4(v0, p.slope);
+        v1 = leaky4(v1, p.slope);
+        const int n = m / (p.Ho * p.Wo), r = m - n * (p.Ho * p.Wo), ho = r / p.Wo, wo = r - ho * p.Wo;
+        if (p.res) {
+            const char* rp = p.res + p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                             wo * p.r_pix_stride + (long long)c0 * (p.res_f32 ? 4 : 2);
+            if (p.res_f32) {
+                v0 += *(const f32x4*)rp;
+                v1 += *(const f32x4*)(rp + 16);
+            } else {
+                const u32x4 rr = *(const u32x4*)rp;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    v0[2 * e] += __uint_as_float(rr[e] << 16);
+                    v0[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                    v1[2 * e] += __uint_as_float(rr[2 + e] << 16);
+                    v1[2 * e + 1] += __uint_as_float(rr[2 + e] & 0xffff0000u);
+                }
+            }
+        }
+        const int up = p.upsample ? 2 : 1;
+        char* yp = p.y + p.y_origin + (long long)n * p.y_img_stride + (long long)(ho * up) * p.y_row_stride +
+                   (wo * up) * p.y_pix_stride + (long long)c0 * (p.y_f32 ? 4 : 2);
+        u32x4 packed;
+        if (!p.y_f32) {
+            packed[0] = pack_bf16x2(v0[0], v0[1]);
+            packed[1] = pack_bf16x2(v0[2], v0[3]);
+            packed[2] = pack_bf16x2(v1[0], v1[1]);
+            packed[3] = pack_bf16x2(v1[2], v1[3]);
+        }
+        for (int dy = 0; dy < up; ++dy)
+            for (int dx = 0; dx < up; ++dx) {
+                char* o = yp + dy * p.y_row_stride + dx * p.y_pix_stride;
+                if (p.y_f32) {
+                    *(f32x4*)o = v0;
+                    *(f32x4*)(o + 16) = v1;
+                } else {
+                    *(u32x4*)o = packed;
+                }
+            }
+    }
+}
+
+// Split-K pays when a layer has too few tiles to occupy the chip and a long k loop: batch 1 (16-58 tiles of 96-192
+// pixels for 256 CUs, 18-72 k-steps each).  splits = how many workgroups share one tile's k range.
+static int splitk_choice(int M, int Cin, int Cout, int k, int dtype, int* tp_out) {
+    if (dtype != YOLO_BF16 || Cin % 64 != 0 || Cout <= 64) return 1;
+    const int nsteps = conv_nsteps(Cin, k, dtype);
+    const int n_ctiles = (Cout + 127) / 128;
+    const int tp = M <= 96 * 4 ? 96 : 128;  // few pixels: the smaller tile wastes less of its last tile
+    const int tiles = ((M + tp - 1) / tp) * n_ctiles;
+    if (tiles >= 128 || nsteps < 8) return 1;  // (a quarter of the resident slots: below it the chip is mostly idle)
+    int splits = 512 / tiles;             // fill the 512 resident workgroup slots once
+    if (splits > nsteps / 4) splits = nsteps / 4;  // at least four k-steps per workgroup
+    if (splits > 16) splits = 16;
+    *tp_out = tp;
+    return splits < 2 ? 1 : splits;
+}
+
+}  // namespace yolo
+
+extern "C" int yolo_conv2d_splitk_plan(int M, int Cin, int Cout, int k, int stride, int dtype, int* splits,
+                                       size_t* workspace_bytes) {
+    YOLO_REQUIRE(M > 0 && Cin > 0 && Cout > 0 && splits && workspace_bytes, "conv2d_splitk_plan: bad argument");
+    int tp = 0;
+    (void)stride;
+    *splits = splitk_choice(M, Cin, Cout, k, dtype, &tp);
+    *workspace_bytes = *splits > 1 ? (size_t)*splits * (size_t)M * (size_t)((Cout + 127) / 128 * 128) * sizeof(float) : 0;
+    return YOLO_OK;
+}
+
+extern "C" int yolo_conv2d_fwd_splitk(const yolo_view* x, const void* w_packed, const float* bias,
+                                      const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
+                                      int stride, float leaky_slope, int upsample2x, int dtype, int y_dtype, void* workspace,
+                                      size_t ws_bytes, void* stream) {
+    YOLO_REQUIRE(x && y && w_packed && bias, "conv2d_splitk: null argument");
+    YOLO_REQUIRE(k == 1 || k == 3, "conv2d_splitk: kernel size %d (1 or 3)", k);
+    YOLO_REQUIRE(stride == 1 || stride == 2, "conv2d_splitk: stride %d (1 or 2)", stride);
+    const int pad = (k - 1) / 2;
+    YOLO_REQUIRE(x->halo >= pad, "conv2d_splitk: input halo %d < pad %d", x->halo, pad);
+    const int Ho = (x->H + 2 * pad - k) / stride + 1, Wo = (x->W + 2 * pad - k) / stride + 1;
+    const long long M = (long long)N * Ho * Wo;
+    YOLO_REQUIRE(M > 0 && M < (1ll << 24), "conv2d_splitk: %lld output pixels", M);
+    int tp = 0;
+    const int splits = splitk_choice((int)M, Cin, Cout, k, dtype, &tp);
+    if (splits <= 1)  // nothing to gain for this shape: the plain launch
+        return yolo_conv2d_fwd(x, w_packed, bias, residual, y, N, Cin, Cout, k, stride, leaky_slope, upsample2x, dtype, y_dtype,
+                               stream);
+    const int up = upsample2x ? 2 : 1;
+    YOLO_REQUIRE(y->H == Ho * up && y->W == Wo * up, "conv2d_splitk: output view %dx%d, expected %dx%d", y->H, y->W, Ho * up,
+                 Wo * up);
+    YOLO_REQUIRE(y_dtype == YOLO_F32 || y_dtype == YOLO_BF16, "conv2d_splitk: y_dtype %d", y_dtype);
+    YOLO_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, "conv2d_splitk: leaky slope %g outside [0, 1]", (double)leaky_slope);
+    const int Cout8 = (Cout + 7) / 8 * 8, Cp = (Cout + 127) / 128 * 128;
+    YOLO_REQUIRE(x->ch_offset + Cin <= x->ch_total && x->ch_offset % 8 == 0 && x->ch_total % 8 == 0,
+                 "conv2d_splitk: bad input channel slice");
+    YOLO_REQUIRE(y->ch_offset + Cout8 <= y->ch_total && y->ch_offset % 8 == 0 && y->ch_total % 8 == 0,
+                 "conv2d_splitk: bad output channel slice");
+    if (residual)
+        YOLO_REQUIRE(!upsample2x && residual->H == Ho && residual->W == Wo && residual->ch_offset % 8 == 0 &&
+                         residual->ch_total % 8 == 0 && residual->ch_offset + Cout8 <= residual->ch_total,
+                     "conv2d_splitk: residual view mismatch");
+    const size_t need = (size_t)splits * (size_t)M * Cp * sizeof(float);
+    YOLO_REQUIRE(workspace && ws_bytes >= need, "conv2d_splitk: workspace %zu < %zu bytes", ws_bytes, need);
+
+    ConvParams p{};
+    p.x = (const char*)x->ptr;
+    p.w = (const char*)w_packed;
+    p.bias = bias;
+    p.y = (char*)workspace;
+    const ViewGeom gx = geom_of(*x), gy = geom_of(*y);
+    p.x_img_stride = gx.img_stride * 2;
+    p.x_row_stride = gx.row_stride * 2;
+    p.x_pix_stride = gx.pix_stride * 2;
+    p.x_origin = ((long long)gx.origin - (long long)pad * gx.row_stride - (long long)pad * gx.pix_stride) * 2;
+    p.y_pix_stride = Cp * 4;  // the slab: [M][Cp] f32, no halo
+    p.y_row_stride = Wo * Cp * 4;
+    p.y_img_stride = (long long)Ho * Wo * Cp * 4;
+    p.y_origin = 0;
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.M = (int)M;
+    p.inv_HoWo = 1.0f / (float)(Ho * Wo);
+    p.inv_Wo = 1.0f / (float)Wo;
+    p.fast_div = 1;
+    p.stride = stride;
+    p.ksize = k;
+    p.cpt = Cin / 64;
+    p.nsteps = k * k * p.cpt;
+    p.w_row_bytes = p.nsteps * ROWB;
+    p.Cout = Cp;  // every channel of the slab is written (padded weight rows are zero)
+    p.slope = 1.0f;
+    p.y_f32 = 1;
+    p.n_ctiles = Cp / 128;
+    p.n_ptiles = (int)((M + tp - 1) / tp);
+    p.split_steps = (p.nsteps + splits - 1) / splits;
+    const int real_splits = (p.nsteps + p.split_steps - 1) / p.split_steps;
+    p.y_split_stride = (long long)M * Cp * 4;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = tp == 96 ? launch_conv_copies<bf16_t, 128, 96>(p, real_splits, st)
+                            : launch_conv_copies<bf16_t, 128, 128>(p, real_splits, st);
+    if (rc != YOLO_OK) return rc;
+
+    SplitReduceParams r{};
+    r.slabs = (const float*)workspace;
+    r.slab_stride = (long long)M * Cp;
+    r.bias = bias;
+    r.res = residual ? (const char*)residual->ptr : nullptr;
+    r.y = (char*)y->ptr;
+    const int yes = (int)elem_size(y_dtype);
+    r.y_img_stride = gy.img_stride * yes;
+    r.y_row_stride = gy.row_stride * yes;
+    r.y_pix_stride = gy.pix_stride * yes;
+    r.y_origin = (long long)gy.origin * yes;
+    if (residual) {
+        const ViewGeom gr = geom_of(*residual);
+        r.r_img_stride = gr.img_stride * 2;
+        r.r_row_stride = gr.row_stride * 2;
+        r.r_pix_stride = gr.pix_stride * 2;
+        r.r_origin = (long long)gr.origin * 2;
+    }
+    r.M = (int)M;
+    r.Ho = Ho;
+    r.Wo = Wo;
+    r.Cout = Cout;
+    r.Cp = Cp;
+    r.splits = real_splits;
+    r.slope = leaky_slope;
+    r.upsample = upsample2x ? 1 : 0;
+    r.y_f32 = y_dtype == YOLO_F32;
+    r.res_f32 = 0;
+    const long long threads = M * ((Cout + 7) / 8);
+    long long blocks = (threads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
 }
 
 extern "C" int yolo_conv_kernel_name(const yolo_view* x, const yolo_view* y, int N, int Cin, int Cout, int k, int stride,

@@ -116,7 +116,9 @@ __device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* k
     __syncthreads();
     if (tid < RADIX_BINS && sh.hist[pass][tid] == (unsigned)m) sh.uniform_digit = 1;
     __syncthreads();
-    if (sh.uniform_digit) return false;
+    const bool uniform = sh.uniform_digit != 0;
+    __syncthreads();  // every thread has read the flag before the next pass's thread 0 clears it
+    if (uniform) return false;
     // exclusive scan of the 256 counts (4 waves)
     unsigned mine = 0, incl = 0;
     if (tid < RADIX_BINS) {
@@ -570,6 +572,7 @@ struct GatherParams {
     float* det;
     int* n_det;
     int keep_stride, N;
+    int cap;  // candidates that exist in the arrays: image starts are clamped to it, as in the NMS
 };
 
 // detector_postprocess: scale by (out_w / in_w, out_h / in_h), clip to the output frame, drop boxes
@@ -577,7 +580,7 @@ struct GatherParams {
 __global__ void __launch_bounds__(64) gather_kernel(const GatherParams p) {
     const int n = blockIdx.x, lane = threadIdx.x;
     const int nk = p.n_keep[n];
-    const int base = p.img_offsets[n];
+    const int base = p.img_offsets[n] < p.cap ? p.img_offsets[n] : p.cap;
     const float in_h = (float)p.in_hw[2 * n], in_w = (float)p.in_hw[2 * n + 1];
     const float out_h = (float)p.out_hw[2 * n], out_w = (float)p.out_hw[2 * n + 1];
     // python: scale = out / in evaluated in double, then the fp32 tensor is multiplied by it
@@ -740,13 +743,13 @@ extern "C" int yolo_batched_nms(const float* boxes, const float* scores, const i
 }
 
 extern "C" int yolo_gather_detections(const float* boxes, const float* scores, const int* classes,
-                                      const int* img_offsets, const int* keep, int keep_stride, const int* n_keep,
-                                      int N, const int* in_hw, const int* out_hw, float* det, int* n_det,
-                                      void* stream) {
+                                      const int* img_offsets, int M_cap, const int* keep, int keep_stride,
+                                      const int* n_keep, int N, const int* in_hw, const int* out_hw, float* det,
+                                      int* n_det, void* stream) {
     YOLO_REQUIRE(boxes && scores && classes && img_offsets && keep && n_keep && in_hw && out_hw && det && n_det,
                  "gather: null argument");
-    YOLO_REQUIRE(N >= 1 && keep_stride > 0, "gather: N %d keep_stride %d", N, keep_stride);
-    GatherParams p{boxes, scores, classes, img_offsets, keep, n_keep, in_hw, out_hw, det, n_det, keep_stride, N};
+    YOLO_REQUIRE(N >= 1 && keep_stride > 0 && M_cap >= 0, "gather: N %d keep_stride %d capacity %d", N, keep_stride, M_cap);
+    GatherParams p{boxes, scores, classes, img_offsets, keep, n_keep, in_hw, out_hw, det, n_det, keep_stride, N, M_cap};
     hipLaunchKernelGGL(gather_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, p);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;

@@ -50,6 +50,7 @@ class Plan:
     cand: Optional[ops.Candidates] = None
     decode_ws: Optional[torch.Tensor] = None
     nms_ws: Optional[torch.Tensor] = None
+    splitk_ws: Dict[str, torch.Tensor] = field(default_factory=dict)  # partial-sum slabs of split-K layers, per stream
     keep: Optional[torch.Tensor] = None
     n_keep: Optional[torch.Tensor] = None
     cand_cap: int = 0  # capacity wanted for the candidate buffers (0: the default of 4096 per image)
@@ -93,6 +94,7 @@ class Yolov3Engine:
         self._bstream = None
         self.branch_on_side_stream = os.environ.get("YOLO_BRANCH_STREAM", "1") != "0"
         self.nms_on_side_stream = os.environ.get("YOLO_NMS_STREAM", "1") != "0"
+        self.split_k = True  # few-pixel layers (small batches) split every tile's k loop over several workgroups
         # measurement hook: when a list, submit()/finish() append (label, start event, end event) recorded on the
         # stream the decode / NMS + gather launches run on
         self.trace_events: Optional[list] = None
@@ -129,6 +131,19 @@ class Yolov3Engine:
             c = pk[name]
             P.flops += 2 * N * (y.H // (2 if up else 1)) * (y.W // (2 if up else 1)) * c.cout * c.cin * c.k * c.k
             P.meta.append(dict(name=name, x=x, y=y, slope=slope, residual=residual, up=up))
+            M = N * (y.H // (2 if up else 1)) * (y.W // (2 if up else 1))
+            splits, nbytes = (ops.conv_splitk_plan(M, c.cin, c.cout, c.k, c.stride, dt)
+                              if dt == torch.bfloat16 and self.split_k else (1, 0))
+            if splits > 1:  # few-pixel layer (small batch): several workgroups share every tile's k loop
+                # the output branches of the two coarse levels run on a stream of their own (run_backbone): their
+                # partial sums must not share a buffer with the main stream's layers
+                key = "branch" if name.startswith(("fpn_output0.", "fpn_output1.")) else "main"
+                if key not in P.splitk_ws or P.splitk_ws[key].numel() < nbytes:
+                    P.splitk_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                P.steps.append(lambda: ops.conv2d_fwd_splitk(x, c.w, c.b, y, P.splitk_ws[key], cin=c.cin, cout=c.cout,
+                                                             k=c.k, stride=c.stride, slope=slope, residual=residual,
+                                                             upsample2x=up))
+                return
             P.steps.append(lambda: ops.conv2d_fwd(x, c.w, c.b, y, cin=c.cin, cout=c.cout, k=c.k, stride=c.stride,
                                                   slope=slope, residual=residual, upsample2x=up))
 

@@ -195,6 +195,30 @@ def conv2d_fwd(x: View, w_packed: torch.Tensor, bias: torch.Tensor, y: View, *, 
     check(code, "yolo_conv2d_fwd")
 
 
+def conv_splitk_plan(M: int, cin: int, cout: int, k: int, stride: int, dtype: torch.dtype) -> Tuple[int, int]:
+    """(splits, workspace bytes) yolo_conv2d_fwd_splitk uses for a convolution with M output pixels; splits == 1 means
+    the plain launch is the better one."""
+    splits, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+    check(lib().yolo_conv2d_splitk_plan(int(M), cin, cout, k, stride, dtype_code(dtype), ctypes.byref(splits),
+                                        ctypes.byref(nbytes)), "yolo_conv2d_splitk_plan")
+    return splits.value, nbytes.value
+
+
+def conv2d_fwd_splitk(x: View, w_packed: torch.Tensor, bias: torch.Tensor, y: View, workspace: torch.Tensor, *, cin: int,
+                      cout: int, k: int, stride: int, slope: float = 0.1, residual: Optional[View] = None,
+                      upsample2x: bool = False) -> None:
+    """conv2d_fwd with the k loop of every tile split over several workgroups (few-pixel layers, e.g. batch 1)."""
+    _require_cuda(x.buf, "conv2d_fwd_splitk")
+    xv, yv = x.c(), y.c()
+    rv = residual.c() if residual is not None else None
+    code = lib().yolo_conv2d_fwd_splitk(ctypes.byref(xv), _ptr(w_packed), _ptr(bias),
+                                        ctypes.byref(rv) if rv is not None else None, ctypes.byref(yv),
+                                        x.N, cin, cout, k, stride, float(slope), int(upsample2x),
+                                        dtype_code(x.buf.dtype), dtype_code(y.buf.dtype), _ptr(workspace),
+                                        workspace.numel() * workspace.element_size(), _stream())
+    check(code, "yolo_conv2d_fwd_splitk")
+
+
 def stem_fwd(images: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: View, *,
              mean: Sequence[float], std: Sequence[float], slope: float = 0.1) -> None:
     """images: [N,3,Hs,Ws] contiguous, float32 or uint8, values 0..255."""
@@ -358,7 +382,7 @@ def gather_detections(cand: Candidates, keep: torch.Tensor, n_keep: torch.Tensor
     det = torch.empty((N, stride, 6), dtype=torch.float32, device=dev)
     n_det = torch.empty((N,), dtype=torch.int32, device=dev)
     code = lib().yolo_gather_detections(_ptr(cand.boxes), _ptr(cand.scores), _ptr(cand.classes),
-                                        _ptr(cand.img_offsets), _ptr(keep), stride, _ptr(n_keep), N,
+                                        _ptr(cand.img_offsets), cand.scores.numel(), _ptr(keep), stride, _ptr(n_keep), N,
                                         _ptr(in_hw), _ptr(out_hw), _ptr(det), _ptr(n_det), _stream())
     check(code, "yolo_gather_detections")
     return det, n_det
