@@ -266,11 +266,12 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
 
 
 def _kernel_source_sha() -> str:
-    """Identifies the kernel sources a PMC record belongs to (hash of yolo_amd/csrc/*.hip and common.h)."""
+    """Identifies the kernel sources a PMC record belongs to: hash of the convolution kernel's source
+    (yolo_amd/csrc/conv.hip) and the headers next to it."""
     import glob
     import hashlib
     h = hashlib.sha1()
-    for path in sorted(glob.glob(os.path.join(ROOT, "yolo_amd", "csrc", "*.hip")) +
+    for path in sorted(glob.glob(os.path.join(ROOT, "yolo_amd", "csrc", "conv.hip")) +
                        glob.glob(os.path.join(ROOT, "yolo_amd", "csrc", "*.h"))):
         with open(path, "rb") as f:
             h.update(f.read())

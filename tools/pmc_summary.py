@@ -32,11 +32,37 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    m = re.search(r"conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d)ELi(\d)ELb(\d)", name)
+    """The name yolo_conv_kernel_name() gives the instance (what bench.py looks up), from the profiler's mangled or
+    demangled kernel name; template arguments: element type, tile channels, tile pixels, wave layout (2), two taps per
+    k-step, waves, BatchNorm sums, stride-2 data gradient, strip form."""
+    m = re.search(r"conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d)ELi(\d)ELb(\d)ELi\d+ELb(\d)ELb(\d)ELb(\d)", name)
     if m:
-        return "conv_igemm_kernel<%s,%s,%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
-                                                        m.group(4), m.group(5), "true" if m.group(6) == "1" else "false")
-    return re.sub(r"^void |\(.*$", "", name).replace("yolo::", "")[:44]
+        g = list(m.groups())
+    else:
+        m = re.search(r"conv_igemm_kernel<([^,]+), *(\d+), *(\d+), *(\d), *(\d), *(\w+), *\d+, *(\w+), *(\w+), *(\w+)>", name)
+        if not m:
+            return re.sub(r"^void |\(.*$", "", name).replace("yolo::", "")[:44]
+        g = list(m.groups())
+        g[0] = "DF16b" if "bfloat" in g[0] else "f"
+        for i in (5, 6, 7, 8):
+            g[i] = "1" if g[i] in ("true", "1") else "0"
+    form = "strip" if g[8] == "1" else ("tap2" if g[5] == "1" else "plain")
+    extra = ("+bnsums" if g[6] == "1" else "") + ("+s2dgrad" if g[7] == "1" else "")
+    return "conv_igemm_kernel<%s,%s,%s,%s,%s,%s>%s" % ("bf16" if g[0] == "DF16b" else "float", g[1], g[2], g[3], g[4], form, extra)
+
+
+def kernel_source_sha():
+    """The same hash bench.py computes: which kernel sources the record belongs to."""
+    import glob
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(root, "yolo_amd", "csrc", "conv.hip")) +
+                       glob.glob(os.path.join(root, "yolo_amd", "csrc", "*.h"))):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -56,7 +82,7 @@ def main():
         recs = {r[0]: dict(kernel=r[0], hbm_bytes_per_launch=round(r[4]), launches_sampled=r[1],
                            fetch_size_kib_per_launch=round(r[2], 1), write_size_kib_per_launch=round(r[3], 1)) for r in convs}
         with open(sys.argv[3], "w") as f:
-            json.dump(dict(kernels=recs, source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py; "
+            json.dump(dict(kernels=recs, kernel_source_sha=kernel_source_sha(), source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py; "
                                                 "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"), f, indent=1)
 
 
