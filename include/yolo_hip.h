@@ -298,6 +298,21 @@ int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N, int Cin, i
 size_t yolo_conv2d_wgrad_workspace_bytes(int M, int Cin, int Cout, int k);
 
 /*
+ * Weight gradient of the stem convolution (3 -> 32 channels, 3x3, stride 1), for training with
+ * MODEL.BACKBONE.FREEZE_AT = 0, where DarkNet.freeze (darknet.py:236-258) leaves BasicStem (darknet.py:40-60)
+ * trainable and the reference obtains this gradient from autograd:
+ *   dw[co][kh][kw][ci] (+)= sum_{n,y,x} dz[n][y][x][co] * xn[n][y+kh-1][x+kw-1][ci]
+ *   img / img_dtype / Hs / Ws / mean_host / std_host   as yolo_stem_fwd: xn = (img - mean) / std, zero outside the image
+ *   dz                 gradient view of the stem's convolution output (32 channels, dz_dtype f32 or bf16)
+ *   round_input_bf16   != 0: xn rounded to bf16, as the bf16 forward kernel multiplies it
+ *   workspace          yolo_stem_wgrad_workspace_bytes()
+ */
+int yolo_stem_wgrad(const void* img, int img_dtype, int N, int Hs, int Ws, const float* mean_host,
+                    const float* std_host, const yolo_view* dz, int dz_dtype, int round_input_bf16, float* dw,
+                    int accumulate, void* workspace, size_t ws_bytes, void* stream);
+size_t yolo_stem_wgrad_workspace_bytes(void);
+
+/*
  * Per-step repacking of a trainable conv's f32 master weights w [Cout][Cin][k][k] (torch layout) into
  *   w_fwd    rows [co][kh][kw][ci] of `fwd_row` elements (what yolo_conv2d_fwd reads), and/or
  *   w_dgrad  rows [ci][kh][kw][co] of `dgrad_row` elements, taps rotated by 180 degrees, co padded to Cout_pad

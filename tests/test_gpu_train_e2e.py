@@ -18,10 +18,10 @@ import workload
 pytestmark = pytest.mark.gpu
 
 
-def _make(dtype, N=4, S=128):
+def _make(dtype, N=4, S=128, freeze_at=2):
     from oracle import yolo_train_ref as T
     from yolo_amd.structures import Boxes, Instances
-    model, cfg = workload.build_model(config="yolov3.yaml", dtype=dtype)
+    model, cfg = workload.build_model(config="yolov3.yaml", dtype=dtype, opts=["MODEL.BACKBONE.FREEZE_AT", freeze_at])
     C = cfg.MODEL.YOLOV3.NUM_CLASSES
     imgs = workload.synthetic_images(N, S, S, seed=3)
     gb, gc = T.synthetic_targets(N, S, C, seed=11, max_boxes=6)
@@ -34,15 +34,18 @@ def _l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def test_training_step_fp32_matches_oracle(cuda):
+@pytest.mark.parametrize("freeze_at", [2, 1, 0])
+def test_training_step_fp32_matches_oracle(cuda, freeze_at):
+    """MODEL.BACKBONE.FREEZE_AT = 2 is the reference's default; 1 trains the first stage too, 0 the stem as well
+    (DarkNet.freeze, darknet.py:236-258)."""
     from oracle import yolo_train_ref as T
-    model, cfg, sd, imgs, gb, gc, inputs = _make("f32")
+    model, cfg, sd, imgs, gb, gc, inputs = _make("f32", freeze_at=freeze_at)
     C = cfg.MODEL.YOLOV3.NUM_CLASSES
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
     full = dict(sd)
     full.update(params)
     stats, heads_ref = {}, {}
-    want = T.forward_training(imgs.float() / 255.0, full, gb, gc, C, freeze_at=2, stats=stats, heads_out=heads_ref)
+    want = T.forward_training(imgs.float() / 255.0, full, gb, gc, C, freeze_at=freeze_at, stats=stats, heads_out=heads_ref)
     sum(want.values()).backward()
     model.train()
     got = model(inputs)
@@ -54,7 +57,7 @@ def test_training_step_fp32_matches_oracle(cuda):
     for name, hv in zip(["p3", "p4", "p5"], P.heads):
         ref = heads_ref[name].detach()
         assert float((hv.nchw().float().cpu() - ref).abs().max() / ref.abs().max()) < 1e-3, name
-    frozen = set(T.frozen_names(2))
+    frozen = set(T.frozen_names(freeze_at))
     n = 0
     for name, p in model.named_parameters():
         layer = name.rsplit(".norm.", 1)[0].rsplit(".weight", 1)[0].rsplit(".bias", 1)[0]
@@ -65,14 +68,18 @@ def test_training_step_fp32_matches_oracle(cuda):
         cos = float(F.cosine_similarity(g.flatten().double(), ref.flatten().double(), dim=0))
         assert cos > 0.998 and _l2(g, ref) < 0.06, (name, cos, _l2(g, ref))
         n += 1
-    assert n == 210
+    assert n == {2: 210, 1: 219, 0: 222}[freeze_at]   # + 3 convolutions of res1 (weight, gamma, beta each), + the stem
     # running statistics moved exactly as torch's BatchNorm2d moves them
     bufs = dict(model.named_buffers())
-    for name in ("backbone.fpn_lateral0.blocks.0", "backbone.bottom_up.res3.2.conv2"):
+    moved = ["backbone.fpn_lateral0.blocks.0", "backbone.bottom_up.res3.2.conv2"]
+    moved += ["backbone.bottom_up.res1.0.conv1"] if freeze_at <= 1 else []
+    moved += ["backbone.bottom_up.stem.conv"] if freeze_at == 0 else []
+    for name in moved:
         assert _l2(bufs[name + ".norm.running_mean"].cpu(), stats[name][0]) < 1e-3
         assert _l2(bufs[name + ".norm.running_var"].cpu(), stats[name][1]) < 1e-3
-    frozen_buf = bufs["backbone.bottom_up.res1.0.conv1.norm.running_mean"].cpu()
-    assert torch.equal(frozen_buf, sd["backbone.bottom_up.res1.0.conv1.norm.running_mean"])
+    for name in ["backbone.bottom_up.stem.conv"] + (["backbone.bottom_up.res1.0.conv1"] if freeze_at >= 2 else []):
+        if freeze_at >= 1:
+            assert torch.equal(bufs[name + ".norm.running_mean"].cpu(), sd[name + ".norm.running_mean"])
     model.eval()
 
 
@@ -80,18 +87,21 @@ def _consumers(P):
     """activation buffer id -> list of (layer, kind) that read it: 'conv' input or 'skip' (residual add)."""
     out = {}
     for L in P.layers:
+        if L.stem:
+            continue  # reads the images
         out.setdefault(id(L.x.buf), []).append((L, "conv"))
         if L.residual is not None:
             out.setdefault(id(L.residual.buf), []).append((L, "skip"))
     return out
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
-def test_training_plan_is_self_consistent(cuda, dtype):
+@pytest.mark.parametrize("dtype,freeze_at", [("bf16", 2), ("f32", 2), ("bf16", 0), ("bf16", 1)])
+def test_training_plan_is_self_consistent(cuda, dtype, freeze_at):
     """Every step of the plan against torch CPU autograd on the plan's OWN tensors: forward conv / BatchNorm / leaky /
     residual of each trainable layer, its dz, dW, dgamma, dbeta, and the accumulated gradient of every activation
-    (sum over all consumers, skip connections, the 2x upsample and the channel concat)."""
-    model, cfg, sd, imgs, gb, gc, inputs = _make(dtype, N=2, S=128)
+    (sum over all consumers, skip connections, the 2x upsample and the channel concat).  FREEZE_AT 1 and 0 add the
+    thin first-stage layers and the stem (which reads the images and has its own forward and weight-gradient kernels)."""
+    model, cfg, sd, imgs, gb, gc, inputs = _make(dtype, N=2, S=128, freeze_at=freeze_at)
     model.train()
     got = model(inputs)
     sum(got.values()).backward()
@@ -106,7 +116,12 @@ def test_training_plan_is_self_consistent(cuda, dtype):
         if L.frozen:
             continue
         c = L.conv
-        x = L.x.nchw().float().cpu()
+        if L.stem:   # the normalised image, as the stem kernel forms it
+            mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(1, 3, 1, 1)
+            std = torch.tensor(cfg.MODEL.PIXEL_STD).view(1, 3, 1, 1)
+            x = q((imgs.float() - mean) / std)
+        else:
+            x = L.x.nchw().float().cpu()
         w = q(c.weight.detach().float().cpu())
         pad = (c.kernel_size - 1) // 2
         if c.norm is None:   # head: conv + bias, f32 output

@@ -99,6 +99,38 @@ def test_conv_wgrad(cuda, shape, dtype):
     assert _rel(dw.permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 1e-3
 
 
+@pytest.mark.parametrize("case", ["u8_bf16", "f32_f32", "u8_f32_padded"])
+def test_stem_wgrad(cuda, case):
+    """Weight gradient of the 3 -> 32 stem convolution straight from the images (normalised on the fly, zero beyond
+    the stored image and at the borders) against torch autograd of F.conv2d on the normalised, padded image."""
+    from yolo_amd import ops
+    u8 = case.startswith("u8")
+    dz_dtype = torch.bfloat16 if case.endswith("bf16") else torch.float32
+    N, Hs, Ws = 3, 37, 45
+    H, W = (64, 64) if case.endswith("padded") else (Hs, Ws)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (N, 3, Hs, Ws), generator=g, dtype=torch.uint8)
+    img = img if u8 else img.float() + torch.rand(N, 3, Hs, Ws, generator=g)
+    mean, std = [103.53, 116.28, 123.675], [57.375, 57.12, 58.395]
+    xn = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    if dz_dtype == torch.bfloat16:
+        xn = xn.bfloat16().float()
+    xn = F.pad(xn, (0, W - Ws, 0, H - Hs))
+    w = torch.zeros(32, 3, 3, 3, requires_grad=True)
+    dz = torch.randn(N, 32, H, W, generator=g).to(dz_dtype).float()
+    F.conv2d(xn, w, None, padding=1).backward(dz)
+    dzv = ops.view_from_nchw(dz.to(cuda), 1, dz_dtype)
+    dw = torch.full((32, 3, 3, 3), 5.0, device=cuda)
+    ws = torch.empty(ops.stem_wgrad_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    kw = dict(mean=mean, std=std, round_input_bf16=dz_dtype == torch.bfloat16)
+    ops.stem_wgrad(img.to(cuda), dzv, dw, ws, **kw)
+    torch.cuda.synchronize()
+    assert _rel(dw.permute(0, 3, 1, 2).cpu(), w.grad) < 1e-4
+    ops.stem_wgrad(img.to(cuda), dzv, dw, ws, accumulate=True, **kw)
+    torch.cuda.synchronize()
+    assert _rel(dw.permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 1e-4
+
+
 @pytest.mark.parametrize("shape", [(64, 128, 3, 1, 9, 7), (128, 64, 1, 1, 9, 7), (64, 128, 3, 2, 14, 10),
                                    (512, 255, 1, 1, 4, 4), (128, 256, 3, 2, 10, 12)], ids=lambda s: "x".join(map(str, s)))
 def test_conv_dgrad_via_fwd_kernel(cuda, shape):

@@ -78,6 +78,9 @@ SIGNATURES = {
     "yolo_conv2d_wgrad": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                   c_void_p]),
     "yolo_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "yolo_stem_wgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _FP, _FP, _VP, c_int, c_int, c_void_p, c_int,
+                                c_void_p, c_size_t, c_void_p]),
+    "yolo_stem_wgrad_workspace_bytes": (c_size_t, []),
     "yolo_train_loss_fwd": (c_int, [_VP, c_int, ctypes.POINTER(c_int), c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),

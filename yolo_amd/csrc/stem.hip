@@ -229,6 +229,114 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const UpParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem (training with MODEL.BACKBONE.FREEZE_AT = 0; the reference leaves it to autograd of
+// BasicStem.forward, darknet.py:40-60, when DarkNet.freeze(0) at darknet.py:236-258 freezes nothing):
+//   dW[co][kh][kw][ci] = sum over (n, y, x) of dz[n][y][x][co] * xn[n][y + kh - 1][x + kw - 1][ci],
+// xn = the normalised image, zero outside the stored image (and, as the forward kernel of the bf16 plan sees it,
+// rounded to bf16 when round_bf16 is set).  HBM-bound: dz is read once (64-128 bytes per pixel), the image three
+// bytes per pixel; 864 sums.  A workgroup walks 16 x 16 pixel tiles; thread = (output channel, group of four
+// (tap, input channel) combinations) keeps its four sums in registers over all its tiles, then leaves them in a row
+// of partial sums that a second kernel folds in a fixed order (no float atomics: results do not depend on timing).
+struct StemWgradParams {
+    const void* img;
+    const char* dz;
+    long long dz_img_stride, dz_origin;  // bytes
+    int dz_row_stride, dz_pix_stride;    // bytes
+    float* partial;                      // [gridDim.x][32 * 27]
+    int N, Hs, Ws, H, W;
+    int tiles_x, tiles_y;
+    long long total_tiles;
+    float mean[3], stdv[3];
+    int round_bf16;
+};
+
+constexpr int SW_T = 16, SW_L = SW_T + 2;
+
+template <typename IMG, typename DZ>
+__global__ void __launch_bounds__(256) stem_wgrad_kernel(const StemWgradParams p) {
+    __shared__ float xs[SW_L * SW_L * 3 + 8];
+    __shared__ float dzs[SW_T * SW_T * 32];
+    const int tid = threadIdx.x, co = tid & 31, grp = tid >> 5;
+    int base[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = grp * 4 + i;  // (kh, kw, ci) flattened; 27..31 are padding
+        live[i] = j < 27;
+        const int jj = live[i] ? j : 0;
+        base[i] = ((jj / 9) * SW_L + (jj / 3) % 3) * 3 + jj % 3;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long plane = (long long)p.Hs * p.Ws;
+    for (long long t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+        const int tx = (int)(t % p.tiles_x);
+        const long long r = t / p.tiles_x;
+        const int ty = (int)(r % p.tiles_y), n = (int)(r / p.tiles_y);
+        const int x0 = tx * SW_T, y0 = ty * SW_T;
+        const IMG* im = (const IMG*)p.img + (long long)n * 3 * plane;
+        __syncthreads();  // the previous tile's reads are done
+        for (int i = tid; i < SW_L * SW_L * 3; i += 256) {
+            const int ci = i % 3, c = (i / 3) % SW_L, rr = i / (3 * SW_L);
+            const int iy = y0 + rr - 1, ix = x0 + c - 1;
+            float v = 0.f;
+            if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) {
+                v = ((float)im[ci * plane + (long long)iy * p.Ws + ix] - p.mean[ci]) / p.stdv[ci];
+                if (p.round_bf16) v = __uint_as_float(pack_bf16x2(v, 0.f) << 16);
+            }
+            xs[i] = v;
+        }
+        for (int i = tid; i < SW_T * SW_T * 4; i += 256) {  // 8 channels per thread and pass
+            const int c8 = i & 3, px = (i >> 2) & (SW_T - 1), py = i >> 6;
+            const int gy = y0 + py, gx = x0 + px;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (gy < p.H && gx < p.W) {
+                const char* a = p.dz + p.dz_origin + (long long)n * p.dz_img_stride + (long long)gy * p.dz_row_stride +
+                                (long long)gx * p.dz_pix_stride + c8 * 8 * (int)sizeof(DZ);
+                if constexpr (sizeof(DZ) == 2) {
+                    const u32x4 u = *(const u32x4*)a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = __uint_as_float(u[e] << 16);
+                        v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+                    }
+                } else {
+                    const f32x4 u0 = *(const f32x4*)a, u1 = *(const f32x4*)(a + 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = u0[e];
+                        v[4 + e] = u1[e];
+                    }
+                }
+            }
+            float* d = &dzs[(py * SW_T + px) * 32 + c8 * 8];
+            *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int px = 0; px < SW_T * SW_T; ++px) {
+            const float d = dzs[px * 32 + co];
+            const int o = ((px >> 4) * SW_L + (px & (SW_T - 1))) * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(d, xs[o + base[i]], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (live[i]) p.partial[(long long)blockIdx.x * 864 + co * 27 + grp * 4 + i] = acc[i];
+}
+
+__global__ void __launch_bounds__(128) stem_wgrad_fold_kernel(const float* partial, int rows, float* dw, int accumulate) {
+    const int o = blockIdx.x * 128 + threadIdx.x;
+    if (o >= 864) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += partial[(long long)r * 864 + o];
+    dw[o] = accumulate ? dw[o] + a : a;
+}
+
 }  // namespace yolo
 
 using namespace yolo;
@@ -280,6 +388,65 @@ extern "C" int yolo_stem_fwd(const void* img, int img_dtype, int N, int Hs, int 
         else
             hipLaunchKernelGGL((stem_kernel<unsigned char, true>), grid, dim3(256), 0, st, p);
     }
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+constexpr int STEM_WGRAD_ROWS = 1024;
+
+extern "C" size_t yolo_stem_wgrad_workspace_bytes(void) { return (size_t)STEM_WGRAD_ROWS * 864 * sizeof(float); }
+
+extern "C" int yolo_stem_wgrad(const void* img, int img_dtype, int N, int Hs, int Ws, const float* mean_host,
+                               const float* std_host, const yolo_view* dz, int dz_dtype, int round_input_bf16, float* dw,
+                               int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    YOLO_REQUIRE(img && mean_host && std_host && dz && dz->ptr && dw && workspace, "stem_wgrad: null argument");
+    YOLO_REQUIRE(img_dtype == 0 || img_dtype == 1, "stem_wgrad: img_dtype %d (0 = f32, 1 = u8)", img_dtype);
+    YOLO_REQUIRE(dz_dtype == YOLO_F32 || dz_dtype == YOLO_BF16, "stem_wgrad: dz dtype %d", dz_dtype);
+    YOLO_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hs <= dz->H && Ws <= dz->W, "stem_wgrad: image %dx%d does not fit dz %dx%d",
+                 Hs, Ws, dz->H, dz->W);
+    YOLO_REQUIRE(dz->ch_offset % 8 == 0 && dz->ch_total % 8 == 0 && dz->ch_offset + 32 <= dz->ch_total,
+                 "stem_wgrad: dz must hold 32 channels (8-aligned slice)");
+    YOLO_REQUIRE(ws_bytes >= yolo_stem_wgrad_workspace_bytes(), "stem_wgrad: workspace %zu < %zu bytes", ws_bytes,
+                 yolo_stem_wgrad_workspace_bytes());
+    const int es = (int)elem_size(dz_dtype);
+    const ViewGeom g = geom_of(*dz);
+    StemWgradParams p{};
+    p.img = img;
+    p.dz = (const char*)dz->ptr;
+    p.dz_img_stride = g.img_stride * es;
+    p.dz_row_stride = (int)(g.row_stride * es);
+    p.dz_pix_stride = (int)(g.pix_stride * es);
+    p.dz_origin = (long long)g.origin * es;
+    p.partial = (float*)workspace;
+    p.N = N;
+    p.Hs = Hs;
+    p.Ws = Ws;
+    p.H = dz->H;
+    p.W = dz->W;
+    p.tiles_x = (dz->W + SW_T - 1) / SW_T;
+    p.tiles_y = (dz->H + SW_T - 1) / SW_T;
+    p.total_tiles = (long long)N * p.tiles_x * p.tiles_y;
+    for (int i = 0; i < 3; ++i) {
+        p.mean[i] = mean_host[i];
+        p.stdv[i] = std_host[i];
+    }
+    p.round_bf16 = round_input_bf16 ? 1 : 0;
+    const int rows = (int)(p.total_tiles < STEM_WGRAD_ROWS ? p.total_tiles : STEM_WGRAD_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)rows), block(256);
+    if (img_dtype == 0) {
+        if (dz_dtype == YOLO_BF16)
+            hipLaunchKernelGGL((stem_wgrad_kernel<float, bf16_t>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((stem_wgrad_kernel<float, float>), grid, block, 0, st, p);
+    } else {
+        if (dz_dtype == YOLO_BF16)
+            hipLaunchKernelGGL((stem_wgrad_kernel<unsigned char, bf16_t>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((stem_wgrad_kernel<unsigned char, float>), grid, block, 0, st, p);
+    }
+    YOLO_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(7), dim3(128), 0, st, (const float*)workspace, rows, dw, accumulate ? 1 : 0);
     YOLO_CHECK_HIP(hipGetLastError());
     return YOLO_OK;
 }

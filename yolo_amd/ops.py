@@ -446,6 +446,29 @@ def conv2d_wgrad(x: View, dz: View, dw: torch.Tensor, workspace: torch.Tensor, *
                                   _stream()), "yolo_conv2d_wgrad")
 
 
+def stem_wgrad_workspace_bytes() -> int:
+    return int(lib().yolo_stem_wgrad_workspace_bytes())
+
+
+def stem_wgrad(images: torch.Tensor, dz: View, dw: torch.Tensor, workspace: torch.Tensor, *, mean: Sequence[float],
+               std: Sequence[float], round_input_bf16: bool, accumulate: bool = False) -> None:
+    """Weight gradient of the 3 -> 32 stem convolution from the images themselves (normalised on the fly, as
+    stem_fwd does) and the gradient of its output; dw: f32 [32, 3, 3, 3] in the library's [cout, kh, kw, cin] layout."""
+    _require_cuda(images, "stem_wgrad")
+    assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == 32 * 27
+    code_dt = {torch.float32: 0, torch.uint8: 1}.get(images.dtype)
+    if code_dt is None:
+        raise ValueError(f"stem_wgrad: image dtype {images.dtype}")
+    N, _, Hs, Ws = images.shape
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    dzv = dz.c()
+    check(lib().yolo_stem_wgrad(_ptr(images), code_dt, N, Hs, Ws, m, s, ctypes.byref(dzv), dtype_code(dz.buf.dtype),
+                                int(round_input_bf16), _ptr(dw), int(accumulate), _ptr(workspace),
+                                workspace.numel() * workspace.element_size(), _stream()), "yolo_stem_wgrad")
+
+
 def pack_conv_dgrad(weight: torch.Tensor, dtype: torch.dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """Packed weights that make yolo_conv2d_fwd compute the DATA gradient of a conv with ``weight``
     [Cout, Cin, k, k]: channels swapped and taps rotated by 180 degrees, zero bias."""

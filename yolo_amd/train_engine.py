@@ -51,6 +51,7 @@ class TLayer:
     z: Optional[View] = None     # conv output before BatchNorm (trainable BN layers)
     residual: Optional[View] = None
     frozen: bool = False
+    stem: bool = False          # the 3-channel first convolution (reads the images, has its own kernels)
     slope: float = LEAKY
     up_dst: Optional[View] = None     # forward: y is also written 2x-upsampled here
     dy: Optional[View] = None         # gradient w.r.t. y
@@ -77,6 +78,8 @@ class TPlan:
     heads: List[View] = field(default_factory=list)       # p3, p4, p5 (f32, 8-padded channels)
     dheads: List[View] = field(default_factory=list)      # bf16 gradient buffers of the heads
     prefix: List[Callable] = field(default_factory=list)  # frozen fused launches after the stem
+    images: Optional[torch.Tensor] = None   # the step's input (a trainable stem's weight gradient reads it again)
+    norm: Optional[tuple] = None             # its (mean, std)
     stem_y: Optional[View] = None
     stem_out: Optional[View] = None
     bn_ws: Optional[torch.Tensor] = None
@@ -96,10 +99,8 @@ class TrainEngine:
         self.device = next(backbone.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("TrainEngine needs the model on an MI355X (cuda device); there is no CPU path")
-        if freeze_at < 2:
-            raise NotImplementedError(
-                "training the stem / first stage (MODEL.BACKBONE.FREEZE_AT < 2) is not built: the 3-channel stem "
-                "has no weight-gradient kernel; the reference's configs freeze both (defaults.py: FREEZE_AT = 2)")
+        if freeze_at < 0:
+            raise ValueError(f"MODEL.BACKBONE.FREEZE_AT = {freeze_at}: must be >= 0")
         self.dtype = dtype  # bf16: the fast path; f32: the 1e-3 parity plan (unfused prefix, FMA weight gradient)
         self.convs = dict(backbone.darknet_modules())
         self.frozen = set()
@@ -162,12 +163,16 @@ class TrainEngine:
         if self._pack_tbl is None:
             entries = []
             for n, c in zip(self._order, convs):
+                if c.in_channels == 3:
+                    continue  # the stem has its own kernels and operand layout
                 b = self._train_bufs(n)
                 entries.append((c.weight.data, b[0], b[1], (c.out_channels + 63) // 64 * 64))
             self._pack_tbl = ops.pack_table(entries, self.device)
         ops.pack_conv_train_batch(*self._pack_tbl, self.dtype)
         for n, c in zip(self._order, convs):
-            if c.bias is not None:
+            if c.in_channels == 3:    # [Cout, 3, kh, kw] -> [kh, kw, 3, Cout], what yolo_stem_fwd reads
+                self._stem_w = c.weight.detach().permute(2, 3, 1, 0).contiguous().float()
+            elif c.bias is not None:
                 self._wbufs[n][2][:c.out_channels].copy_(c.bias.detach())
         self._pack_ver = ver
 
@@ -250,7 +255,8 @@ class TrainEngine:
                 if conv.norm is not None:
                     L.z = A(ho, wo, conv.out_channels, 0)
                     L.stats = torch.zeros(5, conv.out_channels, device=dev)
-                    L.dz = A(ho, wo, conv.out_channels)
+                    wide = A(ho, wo, (conv.out_channels + 63) // 64 * 64)   # zero-padded to what the data-gradient conv reads
+                    L.dz = View(wide.buf, ho, wo, wide.halo, conv.out_channels, 0)
                 if conv.stride == 2 and not (dt == torch.bfloat16 and conv.kernel_size == 3 and conv.in_channels > 64):
                     L.dzd = A(2 * ho, 2 * wo, conv.out_channels)   # zero-dilated dz for the generic data-gradient form
             P.layers.append(L)
@@ -279,6 +285,8 @@ class TrainEngine:
         if not fused_prefix:
             P.stem_out = A(H, W, stem.out_channels)
             x = P.stem_out
+            if "bottom_up.stem.conv" not in self.frozen:
+                add("bottom_up.stem.conv", None, P.stem_out).stem = True
         for si, nb in enumerate(self.blocks, start=1):
             h, w = h // 2, w // 2
             co = chans[si - 1]
@@ -376,14 +384,23 @@ class TrainEngine:
             L.arena_end = end
         n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
         P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
-        n_sums = max(ops.conv_bnsums_rows(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
-                                          L.conv.kernel_size, dt) * 2 * L.conv.out_channels
-                     for L in P.layers if L.z is not None)
-        P.bn_sums = torch.empty(n_sums, device=dev)
-        n_wg = max(ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
-                                             L.conv.kernel_size) for L in P.layers if not L.frozen)
+        n_sums = max([ops.conv_bnsums_rows(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
+                                           L.conv.kernel_size, dt) * 2 * L.conv.out_channels
+                      for L in P.layers if self._sums_in_epilogue(L)], default=0)
+        P.bn_sums = torch.empty(max(n_sums, 1), device=dev)
+        n_wg = max(ops.stem_wgrad_workspace_bytes() if L.stem else
+                   ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels, L.conv.kernel_size)
+                   for L in P.layers if not L.frozen)
         P.wg_ws = torch.empty(n_wg, dtype=torch.uint8, device=dev)
         return P
+
+    def _sums_in_epilogue(self, L: TLayer) -> bool:
+        """Whether the layer's BatchNorm sums come out of its convolution's epilogue.  The thin first-stage layers
+        (32 output channels, or 32 input channels under a 3x3 bf16 filter: kernel instances without that epilogue) and
+        the stem take the separate statistics pass."""
+        c = L.conv
+        return (self.fuse_bn_sums and L.z is not None and not L.stem and c.out_channels > 32
+                and not (self.dtype == torch.bfloat16 and c.in_channels == 32 and c.kernel_size == 3))
 
     @staticmethod
     def _is_conv1(L: TLayer) -> bool:
@@ -402,16 +419,29 @@ class TrainEngine:
         N, _, Hs, Ws = images.shape
         P = self.plan(N, (Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         self._pack_all()
-        stem_w, stem_b = self._packed("bottom_up.stem.conv", "folded")
-        if P.stem_y is not None:
-            dw, db = self._packed("bottom_up.res1.0.downsample", "folded")
-            ops.stem_down_fwd(images.contiguous(), stem_w, stem_b, dw, db, P.stem_y, padded_hw=(P.H, P.W), mean=mean, std=std)
-            for step in P.prefix:
-                step()
+        images = images.contiguous()
+        stem_trainable = bool(P.layers) and P.layers[0].stem
+        if stem_trainable:
+            P.images, P.norm = images, (tuple(mean), tuple(std))  # backward normalises the images again for dW
         else:
-            ops.stem_fwd(images.contiguous(), stem_w, stem_b, P.stem_out, mean=mean, std=std)
+            stem_w, stem_b = self._packed("bottom_up.stem.conv", "folded")
+            if P.stem_y is not None:
+                dw, db = self._packed("bottom_up.res1.0.downsample", "folded")
+                ops.stem_down_fwd(images, stem_w, stem_b, dw, db, P.stem_y, padded_hw=(P.H, P.W), mean=mean, std=std)
+                for step in P.prefix:
+                    step()
+            else:
+                ops.stem_fwd(images, stem_w, stem_b, P.stem_out, mean=mean, std=std)
         for L in P.layers:
             c = L.conv
+            if L.stem:   # normalisation + 3 -> 32 convolution from the images, then batch statistics like any layer
+                n = c.norm
+                rm, rv = (n.running_mean, n.running_var) if update_running_stats else (None, None)
+                ops.stem_fwd(images, self._stem_w, self._zeros(c.out_channels), L.z, mean=mean, std=std, slope=1.0)
+                ops.bn_train_stats(L.z, n.weight.detach(), n.bias.detach(), L.stats, P.bn_ws, eps=n.eps,
+                                   momentum=BN_MOMENTUM, running_mean=rm, running_var=rv)
+                ops.bn_act_fwd(L.z, L.stats, L.y, slope=L.slope)
+                continue
             if L.frozen:
                 w, b = self._packed(L.name, "folded")
                 ops.conv2d_fwd(L.x, w, b, L.y, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size, stride=c.stride,
@@ -424,7 +454,7 @@ class TrainEngine:
                 continue
             n = c.norm
             rm, rv = (n.running_mean, n.running_var) if update_running_stats else (None, None)
-            if self.fuse_bn_sums:   # the conv epilogue leaves per-tile sums of z and z*z: no second pass over z
+            if self._sums_in_epilogue(L):   # the conv epilogue leaves per-tile sums of z and z*z: no second pass over z
                 rows = ops.conv2d_fwd_bnsums(L.x, w, b, L.z, P.bn_sums, cin=c.in_channels, cout=c.out_channels,
                                              k=c.kernel_size, stride=c.stride)
                 ops.bn_train_finalize(P.bn_sums, rows, N * L.z.H * L.z.W, n.weight.detach(), n.bias.detach(), L.stats,
@@ -482,8 +512,12 @@ class TrainEngine:
             if side is not main:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
-                ops.conv2d_wgrad(L.x, dz, L.dW, P.wg_ws, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size,
-                                 stride=c.stride)
+                if L.stem:
+                    ops.stem_wgrad(P.images, dz, L.dW, P.wg_ws, mean=P.norm[0], std=P.norm[1],
+                                   round_input_bf16=self.dtype == torch.bfloat16)
+                else:
+                    ops.conv2d_wgrad(L.x, dz, L.dW, P.wg_ws, cin=c.in_channels, cout=c.out_channels, k=c.kernel_size,
+                                     stride=c.stride)
                 if ddp:
                     P.bucketer.ready(L.arena_end)  # this layer's gradients are final: maybe launch a bucket
             if L.dx is None:
