@@ -98,6 +98,51 @@ def test_grad_bucketer_world2():
     assert launched == [(0, 320), (320, 700), (700, 1000)]        # >= 300 elements per bucket, tail flushed
 
 
+def _direct_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from yolo_amd.utils import dist as D
+    D.init_from_env("gloo")
+    n = 1000
+    g = torch.Generator().manual_seed(rank)
+    arena = torch.randn(n, generator=g)
+    mine = arena.clone()
+    bk = D.GradBucketer(arena, bucket_bytes=300 * 4, mode="direct")
+    assert bk.direct
+    for step in range(2):   # the receive buffers are reused by the second step
+        arena.copy_(mine)
+        bk.start()
+        for end in (100, 250, 320, 700, 990):
+            bk.ready(end)
+        bk.finish()
+    out.put((rank, mine.tolist(), arena.tolist(), bk.launched))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucketer_direct_exchange_world3():
+    """The mesh form of the exchange (every rank sends shard j to rank j, sums its own shard, sends it back to all)
+    on three ranks: the mean of the ranks' arenas, bit-identical on every rank, whole shards per bucket and the
+    remainder (1000 is not a multiple of 3) flushed at the end."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.tensor([g[1] for g in got]).sum(0) / world
+    results = [torch.tensor(g[2]) for g in got]
+    assert all(torch.equal(results[0], r) for r in results[1:])          # bit-identical on every rank
+    assert float((results[0] - want).abs().max()) < 1e-6
+    assert got[0][3] == [(0, 318), (318, 699), (699, 999), (999, 1000)]  # whole shards; one element left for the flush
+    assert all(g[3] == got[0][3] for g in got)
+
+
 def test_grad_bucketer_single_process_is_a_noop():
     from yolo_amd.utils.dist import GradBucketer
     a = torch.ones(10)

@@ -8,7 +8,7 @@ detection counts.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tes
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -103,43 +103,122 @@ def broadcast_tensors(tensors: List[torch.Tensor], src: int = 0, group=None) -> 
 
 
 class GradBucketer:
-    """Bucketed gradient all-reduce over one flat fp32 arena, overlapped with the backward pass.
+    """Bucketed gradient exchange (sum, then mean) over one flat fp32 arena, overlapped with the backward pass.
 
     The training plan lays every parameter gradient out in one arena in the order backward produces them
     (reference: detectron2's DefaultTrainer wraps the model in DistributedDataParallel, tools/train_net.py:127,
     whose reducer buckets gradients in reverse execution order the same way).  ``ready(end)`` says that
-    arena[:end] is final; whenever at least ``bucket_bytes`` are pending, that range goes out as one asynchronous
-    all-reduce on the process group's own stream (RCCL over xGMI on the GPU; gloo in the CPU tests), so the
-    collective runs under the remaining backward kernels.  ``finish()`` flushes the tail, waits and averages.
-    xGMI rings are bound by the per-link rate, so buckets are large (default 64 MiB: 4 buckets for Darknet-53).
+    arena[:end] is final; whenever at least ``bucket_bytes`` are pending, that range goes out asynchronously, so the
+    exchange runs under the remaining backward kernels.  ``finish()`` flushes the tail, waits and averages.
+    Buckets are large (default 64 MiB: 4 buckets for Darknet-53): xGMI transfers are bound by the per-link rate, not
+    by a switch.
+
+    Two ways to exchange a bucket (``mode``, or YOLO_GRAD_EXCHANGE = allreduce | direct | auto):
+
+    * ``allreduce``: one asynchronous all-reduce on the process group's own stream (RCCL picks the schedule).
+    * ``direct``: written for a fully connected xGMI node (every GPU has its own link to each of the 7 others): the
+      bucket is cut into ``world`` equal shards; every rank SENDS shard j to rank j and RECEIVES its own shard from
+      every peer at the same time -- world-1 point-to-point transfers per rank, one per link, grouped into one batch
+      -- sums the ``world`` copies in rank order, and sends the reduced shard back to every peer the same way.  Each
+      link carries 2/world of the bucket, against 2(world-1)/world of it through one link pair for a single ring.
+      Every element is summed by exactly one rank, so all ranks end with bit-identical gradients.  The exchange runs
+      on a stream of its own; a remainder of fewer than ``world`` elements at the arena's end goes out as a small
+      all-reduce.
+    * ``auto`` (default): direct on the nccl (= RCCL) backend from 3 ranks on, all-reduce otherwise.
     """
 
-    def __init__(self, arena: torch.Tensor, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, arena: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, mode: Optional[str] = None):
         assert arena.dim() == 1 and arena.dtype == torch.float32
         self.arena, self.bucket = arena, max(int(bucket_bytes) // 4, 1)
         self.group = group
+        self.mode = (mode or os.environ.get("YOLO_GRAD_EXCHANGE", "auto")).lower()
+        if self.mode not in ("allreduce", "direct", "auto"):
+            raise ValueError(f"gradient exchange mode {self.mode!r}: allreduce, direct or auto")
         self.sent = 0
         self.works = []
         self.launched = []  # (begin, end) of every bucket, for tests / logs
+        self._recv = {}     # bucket begin -> receive buffer [world, shard] of the direct exchange (kept across steps)
+        self._comm = None   # the direct exchange's stream
 
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    @property
+    def direct(self) -> bool:
+        if self.world < 2 or self.mode == "allreduce":
+            return False
+        return self.mode == "direct" or (self.world > 2 and dist.get_backend(self.group) == "nccl")
+
     def start(self) -> None:
         self.sent, self.works, self.launched = 0, [], []
 
-    def _launch(self, end: int) -> None:
+    def _all_reduce(self, piece: torch.Tensor) -> None:
+        if _host_staged(piece, self.group):
+            host = piece.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            piece.copy_(host)
+        else:
+            self.works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _peer(self, j: int) -> int:
+        return j if self.group is None else dist.get_global_rank(self.group, j)
+
+    def _exchange_direct(self, begin: int, piece: torch.Tensor) -> None:
+        """Direct reduce-scatter + all-gather of ``piece`` (numel divisible by world) by grouped point-to-point sends."""
+        W, r = self.world, dist.get_rank(self.group)
+        staged = _host_staged(piece, self.group)
+        buf = piece.cpu() if staged else piece
+        shards = buf.view(W, -1)
+        key = (begin, buf.numel(), buf.device)
+        recv = self._recv.get(key)
+        if recv is None:
+            recv = self._recv[key] = torch.empty_like(shards)
+        peers = [(r + d) % W for d in range(1, W)]
+
+        def run():
+            first = []
+            for j in peers:
+                first.append(dist.P2POp(dist.isend, shards[j], self._peer(j), self.group))
+                first.append(dist.P2POp(dist.irecv, recv[j], self._peer(j), self.group))
+            for w in dist.batch_isend_irecv(first):
+                w.wait()   # on a GPU: the current stream waits, not the host
+            recv[r].copy_(shards[r])
+            torch.sum(recv, dim=0, out=shards[r])   # rank order, whatever the arrival order
+            second = []
+            for j in peers:
+                second.append(dist.P2POp(dist.isend, shards[r], self._peer(j), self.group))
+                second.append(dist.P2POp(dist.irecv, shards[j], self._peer(j), self.group))
+            return dist.batch_isend_irecv(second)
+
+        if buf.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(buf.device)
+            self._comm.wait_stream(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(self._comm):
+                self.works.extend(run())
+        else:
+            for w in run():
+                w.wait()
+            if staged:
+                piece.copy_(buf)
+
+    def _launch(self, end: int, flush: bool = False) -> None:
         if end <= self.sent:
             return
         if self.world > 1:
-            piece = self.arena[self.sent:end]
-            if _host_staged(piece, self.group):
-                host = piece.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                piece.copy_(host)
-            else:
-                self.works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.direct:
+                n = (end - self.sent) // self.world * self.world   # whole shards; the rest waits for the next bucket
+                if n:
+                    self._exchange_direct(self.sent, self.arena[self.sent:self.sent + n])
+                    self.launched.append((self.sent, self.sent + n))
+                    self.sent += n
+                if flush and self.sent < end:                        # fewer than `world` elements at the very end
+                    self._all_reduce(self.arena[self.sent:end])
+                    self.launched.append((self.sent, end))
+                    self.sent = end
+                return
+            self._all_reduce(self.arena[self.sent:end])
         self.launched.append((self.sent, end))
         self.sent = end
 
@@ -148,9 +227,11 @@ class GradBucketer:
             self._launch(end)
 
     def finish(self) -> None:
-        self._launch(self.arena.numel())
+        self._launch(self.arena.numel(), flush=True)
         for w in self.works:
             w.wait()
+        if self._comm is not None and self.arena.is_cuda:
+            torch.cuda.current_stream(self.arena.device).wait_stream(self._comm)
         if self.world > 1:
             self.arena.mul_(1.0 / self.world)
         self.works = []
