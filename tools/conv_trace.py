@@ -27,9 +27,14 @@ def main():
     y = ops.alloc_view(N, Ho, Ho, cout, 1, torch.bfloat16, dev)
     r = ops.alloc_view(N, Ho, Ho, cout, 1, torch.bfloat16, dev) if res else None
     run = lambda: ops.conv2d_fwd(x, wp, bp, y, cin=cin, cout=cout, k=k, stride=s, residual=r)
-    for _ in range(5):
+    import time
+    t_end = time.time() + float(os.environ.get("YOLO_TRACE_WARM_SECONDS", "2"))
+    while time.time() < t_end:   # the clock the chip settles at under this load, not the one of a cold start
+        for _ in range(50):
+            run()
+        torch.cuda.synchronize()
+    for _ in range(200):         # the traced launch follows a full queue directly
         run()
-    torch.cuda.synchronize()
     path = "/tmp/conv_trace.txt"
     os.environ["YOLO_CONV_TRACE_DUMP"] = path
     run()
@@ -47,6 +52,13 @@ def main():
     for name, col in zip(("prologue (entry -> first operands)", "loop", "epilogue (+ store drain)", "whole tile"), ph.T):
         q = np.percentile(col, [5, 50, 95])
         print(f"  {name:36s} mean {col.mean():7.2f}  p5 {q[0]:7.2f}  p50 {q[1]:7.2f}  p95 {q[2]:7.2f} us")
+    if len(rows[0]) >= 12:   # shader cycles over the loop / constant-clock ticks over the loop
+        cyc = np.array([int(r[11]) for r in rows], dtype=np.float64)
+        ticks = (t[:, 2] - t[:, 1]).astype(np.float64)
+        ok = ticks > 0
+        ghz = cyc[ok] / ticks[ok] * 0.1
+        print(f"  shader clock inside the loop: median {np.median(ghz):.2f} GHz (p5 {np.percentile(ghz, 5):.2f}, "
+              f"p95 {np.percentile(ghz, 95):.2f})")
     if len(rows[0]) >= 11:   # set-up part of the prologue
         d = (np.array([int(r[10]) for r in rows], dtype=np.int64) - t0) / 100.0 - us[:, 0]
         print(f"    prologue: entry -> addresses ready {d.mean():5.2f} us (p5 {np.percentile(d, 5):5.2f}, p95 {np.percentile(d, 95):5.2f})")

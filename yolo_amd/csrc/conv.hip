@@ -63,9 +63,14 @@ constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
 // tile staged in LDS / stores issued; slot 9: addresses ready, before the first operand loads are issued.
 constexpr int TRACE_MAX = 1 << 15;
 __device__ unsigned long long g_trace[TRACE_MAX * 10];
+// shader-clock counter at the loop's first and last stamp: cycles / (10 ns ticks) x 100 MHz = the clock the CU held
+__device__ unsigned long long g_cycles[TRACE_MAX * 2];
 #define TRACE_MARK(i)                                                                      \
     do {                                                                                   \
-        if (threadIdx.x == 0 && blockIdx.x < TRACE_MAX) g_trace[blockIdx.x * 10 + (i)] = wall_clock64(); \
+        if (threadIdx.x == 0 && blockIdx.x < TRACE_MAX) {                                  \
+            g_trace[blockIdx.x * 10 + (i)] = wall_clock64();                               \
+            if ((i) == 1 || (i) == 2) g_cycles[blockIdx.x * 2 + (i) - 1] = __builtin_readcyclecounter(); \
+        }                                                                                  \
     } while (0)
 #else
 #define TRACE_MARK(i) \
@@ -765,15 +770,19 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, int copies = 1) 
         const int n = nblocks < TRACE_MAX ? nblocks : TRACE_MAX;
         unsigned long long* h = (unsigned long long*)malloc((size_t)n * 10 * 8);
         YOLO_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), (size_t)n * 10 * 8));
+        unsigned long long* hc = (unsigned long long*)malloc((size_t)n * 2 * 8);
+        YOLO_CHECK_HIP(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_cycles), (size_t)n * 2 * 8));
         FILE* f = fopen(getenv("YOLO_CONV_TRACE_DUMP"), "w");
         if (f) {
             fprintf(f, "# tile %dx%d nsteps %d blocks %d\n", TC, TP, p.nsteps, nblocks);
             for (int i = 0; i < n; ++i)
-                fprintf(f, "%d %llu %llu %llu %llu %llx %llu %llu %llu %llu %llu\n", i, h[10 * i], h[10 * i + 1], h[10 * i + 2],
-                        h[10 * i + 3], h[10 * i + 4], h[10 * i + 5], h[10 * i + 6], h[10 * i + 7], h[10 * i + 8], h[10 * i + 9]);
+                fprintf(f, "%d %llu %llu %llu %llu %llx %llu %llu %llu %llu %llu %llu\n", i, h[10 * i], h[10 * i + 1],
+                        h[10 * i + 2], h[10 * i + 3], h[10 * i + 4], h[10 * i + 5], h[10 * i + 6], h[10 * i + 7], h[10 * i + 8],
+                        h[10 * i + 9], hc[2 * i + 1] - hc[2 * i]);
             fclose(f);
         }
         free(h);
+        free(hc);
     }
 #endif
     return YOLO_OK;
