@@ -272,3 +272,21 @@ def test_unported_augmentations_say_so():
         from yolo_amd.data.transforms import PixelDropoutTransform  # noqa: F401
     with pytest.raises(ImportError):
         from yolo_amd.data import NoSuchThing  # noqa: F401
+
+
+def test_reference_package_name_resolves_to_the_same_modules():
+    """Code written against the reference imports ``yolo.*`` (tools/inference.py:12-13, tools/train_net.py:19-21 of the
+    reference): the alias package hands out the very module objects of yolo_amd, so registries are filled once."""
+    import importlib
+    import yolo
+    import yolo_amd
+    for name in ("config", "checkpoint", "modeling", "data", "modeling.backbone.fpn", "modeling.backbone.darknet",
+                 "modeling.meta_arch.yolo", "modeling.anchor_generator", "modeling.box_regression", "modeling.matcher",
+                 "data.dataset_mapper", "data.transforms", "checkpoint.load_darknet"):
+        assert importlib.import_module("yolo." + name) is importlib.import_module("yolo_amd." + name), name
+    from yolo.config import get_cfg
+    from yolo.checkpoint import YOLOV3Checkpointer
+    assert get_cfg is yolo_amd.config.get_cfg and YOLOV3Checkpointer is yolo_amd.checkpoint.YOLOV3Checkpointer
+    assert yolo.modeling is yolo_amd.modeling
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("yolo.no_such_module")
