@@ -152,7 +152,7 @@ class Yolov3Inference:
     def roofline(self) -> dict:
         plan = self.eng.plan(BATCH, SIZE, SIZE)
         convs = dict(self.model.backbone.darknet_modules())
-        return _dominant_kernel_roofline(self.eng, plan, convs, self.imgs, self.mean, self.std)
+        return _dominant_kernel_roofline(self.eng, plan, convs, self.run)
 
     def postproc(self) -> dict:
         return _postproc_in_step(self)
@@ -170,14 +170,14 @@ class Yolov3Inference:
             return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
-def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int = 3):
+def _dominant_kernel_roofline(eng, plan, convs, step_fn, in_step_steps: int = 8, passes: int = 3):
     """The convolutions run as instances of one implicit-GEMM kernel that differ in their workgroup tile
     (yolo_conv_kernel_name says which launch uses which).  Every launch of the instances with 128 or more channels
-    per tile is timed where it runs: the whole plan is replayed in order with a HIP event
-    pair (on the launch stream) around each of them, so every launch sees the cache state it sees in a real step;
-    the cost of an empty event pair is measured the same way and subtracted.  The instance with the most time is
-    the dominant kernel: achieved = its algorithmic FLOPs (2 * pixels * Cout * Cin * k * k per launch) / its time.
-    The other instances are reported next to it."""
+    per tile is timed where it runs IN THE BENCHMARK'S OWN STEPS: ``step_fn(n)`` runs n pipelined steps while the engine
+    records a HIP event pair (on the launch stream) around each convolution, so every launch sees the cache state and
+    the co-running post-processing kernels it sees in the timed region; the cost of an empty event pair is measured
+    and subtracted.  The instance with the most time is the dominant kernel: achieved = its algorithmic FLOPs
+    (2 * pixels * Cout * Cin * k * k per launch) / its time.  The other instances are reported next to it."""
     import torch
     from yolo_amd import ops
     stream = torch.cuda.current_stream()
@@ -200,26 +200,28 @@ def _dominant_kernel_roofline(eng, plan, convs, images, mean, std, passes: int =
               + (M * c.out_channels * es if meta["residual"] is not None else 0))
         timed.append((i, name, 2.0 * M * c.out_channels * c.in_channels * c.kernel_size ** 2, by, c.kernel_size))
     which = {i: k for k, (i, _, _, _, _) in enumerate(timed)}
+    # (1) inside real pipelined steps: the engine records an event pair around every convolution launch on the stream
+    #     it runs on, while decode / NMS of the previous batch run on their streams -- what a profiler of the bench sees
     ms = [0.0] * len(timed)
+    count = [0] * len(timed)
     empty = 0.0
+    eng.trace_events = []
+    step_fn(in_step_steps)
+    torch.cuda.synchronize()
+    events, eng.trace_events = eng.trace_events, None
+    for label, a, b in events:
+        if isinstance(label, tuple) and label[0] == "conv" and label[1] in which:
+            k = which[label[1]]
+            ms[k] += a.elapsed_time(b)
+            count[k] += 1
+    # (2) the cost of an empty event pair, measured on the idle stream and subtracted
     for _ in range(passes):
-        pairs = [(ev(), ev()) for _ in timed]
         e0, e1 = ev(), ev()
-        eng.run_backbone_prefix(images, mean, std, plan)  # fused stem + first-stage launches
-        for i, step in enumerate(plan.steps):
-            k = which.get(i)
-            if k is None:
-                step()
-            else:
-                pairs[k][0].record(stream)
-                step()
-                pairs[k][1].record(stream)
         e0.record(stream)
         e1.record(stream)
         torch.cuda.synchronize()
         empty += e0.elapsed_time(e1) / passes
-        for k, (a, b) in enumerate(pairs):
-            ms[k] += a.elapsed_time(b) / passes
+    ms = [t / max(c, 1) for t, c in zip(ms, count)]
     acc, by_k = {}, {}
     for (i, name, fl, by, ks), t in zip(timed, ms):
         for a in (acc.setdefault(name, [0.0, 0.0, 0, 0.0]), by_k.setdefault((name, ks), [0.0, 0.0, 0, 0.0])):

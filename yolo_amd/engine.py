@@ -236,8 +236,12 @@ class Yolov3Engine:
             padded_hw = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
         P = plan if plan is not None else self.plan(N, padded_hw[0], padded_hw[1])
         self.run_backbone_prefix(images, mean, std, P)
+        if self.trace_events is not None:   # measurement: an event pair around every convolution launch, where it runs
+            steps = [lambda i=i, step=step: self._traced(("conv", i), step) for i, step in enumerate(P.steps)]
+        else:
+            steps = P.steps
         if not self.branch_on_side_stream:
-            for step in P.steps:
+            for step in steps:
                 step()
             return P
         # The output branches of the two coarse levels (3x3 conv + head conv, fpn.py:96-100) depend only on their
@@ -245,7 +249,7 @@ class Yolov3Engine:
         # the upsample conv and the next level's lateral block (few-tile layers that leave CUs idle on their own).
         main = torch.cuda.current_stream(self.device)
         side = self._branch_stream()
-        for meta, step in zip(P.meta, P.steps):
+        for meta, step in zip(P.meta, steps):
             name = meta["name"]
             if name.startswith(("fpn_output0.", "fpn_output1.")):
                 if name.endswith(".conv"):
@@ -368,6 +372,11 @@ class Yolov3Engine:
         total = int(h.cand.img_offsets[h.plan.N].item())
         return max(0, total - h.cand.scores.numel())
 
+    def _traced(self, label, fn) -> None:
+        t0 = self._trace_begin()
+        fn()
+        self._trace_end(label, t0)
+
     def _trace_begin(self):
         if self.trace_events is None:
             return None
@@ -375,7 +384,7 @@ class Yolov3Engine:
         ev.record()
         return ev
 
-    def _trace_end(self, label: str, start) -> None:
+    def _trace_end(self, label, start) -> None:
         if start is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
