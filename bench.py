@@ -170,7 +170,7 @@ class Yolov3Inference:
             return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
-def _dominant_kernel_roofline(eng, plan, convs, step_fn, in_step_steps: int = 8, passes: int = 3):
+def _dominant_kernel_roofline(eng, plan, convs, step_fn, in_step_steps: int = 12, passes: int = 3):
     """The convolutions run as instances of one implicit-GEMM kernel that differ in their workgroup tile
     (yolo_conv_kernel_name says which launch uses which).  Every launch of the instances with 128 or more channels
     per tile is timed where it runs IN THE BENCHMARK'S OWN STEPS: ``step_fn(n)`` runs n pipelined steps while the engine
@@ -202,26 +202,26 @@ def _dominant_kernel_roofline(eng, plan, convs, step_fn, in_step_steps: int = 8,
     which = {i: k for k, (i, _, _, _, _) in enumerate(timed)}
     # (1) inside real pipelined steps: the engine records an event pair around every convolution launch on the stream
     #     it runs on, while decode / NMS of the previous batch run on their streams -- what a profiler of the bench sees
-    ms = [0.0] * len(timed)
-    count = [0] * len(timed)
-    empty = 0.0
+    samples = [[] for _ in timed]
     eng.trace_events = []
     step_fn(in_step_steps)
     torch.cuda.synchronize()
     events, eng.trace_events = eng.trace_events, None
     for label, a, b in events:
         if isinstance(label, tuple) and label[0] == "conv" and label[1] in which:
-            k = which[label[1]]
-            ms[k] += a.elapsed_time(b)
-            count[k] += 1
-    # (2) the cost of an empty event pair, measured on the idle stream and subtracted
-    for _ in range(passes):
+            samples[which[label[1]]].append(a.elapsed_time(b))
+    # (2) the cost of an empty event pair (median of many, recorded back to back behind a kernel so that the stream
+    #     is busy as in a step), subtracted from every timed launch
+    pairs = []
+    for _ in range(16 * passes):
+        plan.steps[timed[0][0]]()
         e0, e1 = ev(), ev()
         e0.record(stream)
         e1.record(stream)
-        torch.cuda.synchronize()
-        empty += e0.elapsed_time(e1) / passes
-    ms = [t / max(c, 1) for t, c in zip(ms, count)]
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    empty = statistics.median(a.elapsed_time(b) for a, b in pairs)
+    ms = [statistics.median(v) if v else 0.0 for v in samples]   # per launch: median over the traced steps
     acc, by_k = {}, {}
     for (i, name, fl, by, ks), t in zip(timed, ms):
         for a in (acc.setdefault(name, [0.0, 0.0, 0, 0.0]), by_k.setdefault((name, ks), [0.0, 0.0, 0, 0.0])):
