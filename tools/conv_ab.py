@@ -11,7 +11,8 @@ from yolo_amd import _lib, ops  # noqa: E402
 # (Cin, Cout, k, stride, H, residual): the 3x3 / stride-1 layers of Darknet-53 + neck at 416 x 416 and a few others
 LAYERS = [(64, 128, 3, 1, 104, 1), (128, 256, 3, 1, 52, 1), (128, 256, 3, 1, 52, 0), (256, 512, 3, 1, 26, 1),
           (256, 512, 3, 1, 26, 0), (512, 1024, 3, 1, 13, 1), (512, 1024, 3, 1, 13, 0),
-          (256, 128, 1, 1, 52, 0), (512, 256, 1, 1, 26, 0), (256, 512, 3, 2, 52, 0)]
+          (256, 128, 1, 1, 52, 0), (512, 256, 1, 1, 26, 0), (256, 512, 3, 2, 52, 0), (1024, 512, 1, 1, 13, 0),
+          (128, 64, 1, 1, 104, 0), (512, 1024, 3, 2, 26, 0)]
 
 
 def main():

@@ -487,6 +487,78 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     const int adv_rows = PPP / p.Wo, adv_cols = PPP - adv_rows * p.Wo;  // PPP pixels = adv_rows rows + adv_cols columns
     const int jmp_rows = (PPP + JUMP) / p.Wo, jmp_cols = (PPP + JUMP) - jmp_rows * p.Wo;
     const bool tiny = jmp_rows + 1 > p.Ho;
+    // ---- bf16 output without residual (two launches of three): the tile is rounded in registers and staged as bf16
+    //      -- half the LDS bytes, and a 128 x 192 tile (48 KB) goes through in ONE piece instead of two halves: one
+    //      barrier pair less.  Same values as the f32-staged path (LeakyReLU in f32, one rounding).
+    if constexpr (BF && TC == 128 && !STATS && !TAP2 && !STRIP) {
+        if (!p.res && !p.y_f32 && !p.upsample && !p.split_steps && adv_rows + 1 <= p.Ho) {
+            constexpr int NPB = TP / PPP;
+            __syncthreads();  // every wave is done with the operand buffers
+            {
+                const int ch0 = wc * (TC / WC) + q * 4;
+                const int px0 = wp * (TP / WP) + l15;
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const int ch = ch0 + i * 16;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) {
+                        const int px = px0 + j * 16;
+                        const f32x4 v = leaky4(acc[i][j], p.slope);
+                        u32x2 pk;
+                        pk[0] = pack_bf16x2(v[0], v[1]);
+                        pk[1] = pack_bf16x2(v[2], v[3]);
+                        // pixel row = 256 bytes; 16-byte chunk c of pixel px sits at chunk c ^ (px & 15)
+                        *(u32x2*)(smem + px * 256 + ((((ch >> 3) ^ px) & 15) << 4) + ((ch >> 2) & 1) * 8) = pk;
+                    }
+                }
+            }
+            __syncthreads();
+            TRACE_MARK(5);
+            const int m0 = pix_base + prow;
+            int n, ho, wo;
+            split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n, ho, wo);
+            u32x4 sv[NPB];
+#pragma unroll
+            for (int pass = 0; pass < NPB; ++pass) {
+                const int px = pass * PPP + prow;
+                sv[pass] = *(const u32x4*)(smem + px * 256 + (((g ^ px) & 15) << 4));
+            }
+#pragma unroll
+            for (int pass = 0; pass < NPB; ++pass) {
+                bool lv = m0 + pass * PPP < pix_end && ch_first < p.Cout;
+                int oh = ho, ow = wo;
+                if constexpr (STRIP) {  // position column -> pixel column; the two halo columns store nothing
+                    lv = lv && wo >= 1 && wo <= p.Wreal;
+                    ow = wo - 1 < 0 ? 0 : (wo - 1 >= p.Wreal ? p.Wreal - 1 : wo - 1);
+                }
+                if constexpr (S2D) {
+                    oh = 2 * ho + par_a;
+                    ow = 2 * wo + par_b;
+                }
+                char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)oh * p.y_row_stride +
+                           ow * p.y_pix_stride + (size_t)ch_first * 2;
+                if (lv) *(u32x4*)yp = sv[pass];
+                if (pass + 1 < NPB) {
+                    wo += adv_cols;
+                    ho += adv_rows;
+                    if (wo >= p.Wo) {
+                        wo -= p.Wo;
+                        ++ho;
+                    }
+                    if (ho >= p.Ho) {
+                        ho -= p.Ho;
+                        ++n;
+                    }
+                }
+            }
+            TRACE_MARK(6);
+#ifdef YOLO_CONV_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TRACE_MARK(3);
+#endif
+            return;
+        }
+    }
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
     // Output position of each of this lane's passes: one pixel -> (image, row, column) split for the first pass,
