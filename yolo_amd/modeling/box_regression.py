@@ -1,43 +1,48 @@
-"""Box <-> delta transform of the YOLO head (reference yolo/modeling/box_regression.py:12-64).
+"""Box <-> delta transform of the YOLO head.
 
-Inference decodes inside the HIP decode kernel (yolo_amd/csrc/decode.hip); ``apply_deltas`` here is the
-same arithmetic as torch ops for callers that hold explicit delta / anchor tensors (it runs on whatever
-device the tensors are on and is not part of the timed inference path).  ``get_deltas`` builds training
-targets.
+Interface and arithmetic of reference yolo/modeling/box_regression.py:12-64 (``Box2BoxTransform(weights,
+scale_clamp)`` with ``get_deltas`` / ``apply_deltas``), written here on (centre, size) pairs.  Inference decodes
+inside the HIP decode kernel (yolo_amd/csrc/decode.hip) and the training step's targets are formed inside
+``yolo_train_loss_fwd`` (yolo_amd/csrc/loss.hip); this class serves callers that hold explicit delta / anchor tensors
+and the tests of those kernels.  Every operation keeps the reference's order, so results are bit-identical to it.
 """
-from typing import Tuple
+from typing import Sequence, Tuple
 
 import torch
 
 from ..structures import Boxes
 
 
+def _centre_size(xyxy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(x0, y0, x1, y1) -> (centre [.., 2], size [.., 2]); the centre is corner + size / 2, as the reference forms it."""
+    size = xyxy[..., 2:] - xyxy[..., :2]
+    return xyxy[..., :2] + size / 2, size
+
+
 class Box2BoxTransform:
     def __init__(self, weights: Tuple[float, float, float, float], scale_clamp: float):
         self.weights = weights
-        self.scale_clamp = scale_clamp  # stored, never applied: exp() is unclamped (reference :16,:53)
+        self.scale_clamp = scale_clamp  # kept for the config surface; exp() is not clamped (reference :16, :53)
 
-    def get_deltas(self, src_boxes: torch.Tensor, target_boxes, strides: torch.Tensor) -> torch.Tensor:
-        """src_boxes: matched ground truth [N, R, 4]; target_boxes: list of per-level anchor Boxes;
-        strides: [R].  xy target = frac(gt_centre / stride) - 0.5, wh target = log(gt_wh / anchor_wh + 1e-16)."""
-        gt_wh = src_boxes[..., 2:] - src_boxes[..., :2]
-        gt_cxy = src_boxes[..., :2] + gt_wh / 2
-        anchors = Boxes.cat(target_boxes).tensor
-        anchors_wh = anchors[..., 2:] - anchors[..., :2]
-        gt_cxy = gt_cxy / strides[..., None]
-        d_cxy = gt_cxy - torch.floor(gt_cxy) - 0.5
-        d_wh = torch.log(gt_wh / anchors_wh[None, :, :] + 1e-16)
+    def get_deltas(self, src_boxes: torch.Tensor, target_boxes: Sequence[Boxes], strides: torch.Tensor) -> torch.Tensor:
+        """Regression targets.  src_boxes: matched ground truth [N, R, 4]; target_boxes: the per-level anchor Boxes
+        (R anchors in all); strides: [R].  Offsets: position of the box centre inside its grid cell minus one half;
+        sizes: log(box size / anchor size + 1e-16)."""
+        centre, size = _centre_size(src_boxes)
+        _, anchor_size = _centre_size(Boxes.cat(list(target_boxes)).tensor)
+        cell = centre / strides[..., None]
+        offset = cell - torch.floor(cell) - 0.5
+        log_size = torch.log(size / anchor_size[None, :, :] + 1e-16)
         wx, wy, ww, wh = self.weights
-        # the reference multiplies dw by wh and dh by ww (:37-38); identical for unit weights
-        return torch.stack((wx * d_cxy[..., 0], wy * d_cxy[..., 1], wh * d_wh[..., 0], ww * d_wh[..., 1]), dim=-1)
+        # the width term is scaled by the height weight and vice versa, as in the reference (:37-38)
+        scale = offset.new_tensor([wx, wy, wh, ww])
+        return torch.cat((offset, log_size), dim=-1) * scale
 
     def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor, stride: int) -> torch.Tensor:
-        boxes = boxes.to(deltas.dtype)
-        boxes_wh = boxes[:, 2:] - boxes[:, :2]
-        boxes_cxy = boxes[:, :2] + boxes_wh / 2
-        target_cxy = deltas[:, :2] * stride + boxes_cxy
-        target_wh = boxes_wh * deltas[..., 2:].exp()
+        """Boxes of ONE pyramid level from its deltas [R, 4] and anchors [R, 4] (xyxy): centre = delta * stride +
+        anchor centre, size = anchor size * exp(delta), both divided by their weights."""
+        anchor_centre, anchor_size = _centre_size(boxes.to(deltas.dtype))
         wx, wy, ww, wh = self.weights
-        cx, cy = target_cxy[:, 0] / wx, target_cxy[:, 1] / wy
-        w, h = target_wh[:, 0] / ww, target_wh[:, 1] / wh
-        return torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], dim=-1)
+        centre = (deltas[:, :2] * stride + anchor_centre) / deltas.new_tensor([wx, wy])
+        half = anchor_size * deltas[..., 2:].exp() / deltas.new_tensor([ww, wh]) / 2
+        return torch.cat((centre - half, centre + half), dim=-1)
