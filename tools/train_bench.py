@@ -43,6 +43,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = tr.run_step()
+    host = time.perf_counter() - t0   # the host's part: everything queued, nothing awaited
     D.barrier()
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, model.device)
@@ -56,6 +57,7 @@ def main():
         print(json.dumps({
             "metric": "train images/sec (fwd + bwd + all-reduce + SGD)", "value": round(world * args.batch * args.steps / dt, 1),
             "n_gpus": world, "batch_per_gpu": args.batch, "size": args.size, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "host_ms_per_step": round(host / args.steps * 1e3, 2),
             "conv_tflops": round(train_flop * world * args.batch * args.steps / dt / 1e12, 1),
             "losses": {k: round(float(v), 4) for k, v in losses.items()}, "dtype": "bf16", "freeze_at": eng.freeze_at, "params_in_sync": bool(in_sync),
             "config": args.config}))

@@ -161,27 +161,49 @@ class YOLOV3(nn.Module):
             raise RuntimeError("yolo_amd runs on MI355X only (MODEL.DEVICE must be 'cuda'); there is no CPU fallback")
         assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
         batch, _ = self._batch_images(batched_inputs)
-        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         if self.fused_loss and list(self.matcher_labels) == [-1, 0, 1]:
-            return self._fused_training_step(batch, gt_instances)
+            return self._fused_training_step(batch, [x["instances"] for x in batched_inputs])
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         feats = self.backbone.forward_train(batch, self._mean, self._std)
         features = [feats[f] for f in self.head_in_features]
         predictions = self.head(features)
         return self.forward_training(batch, features, predictions, gt_instances)
 
     def _padded_targets(self, gt_instances: List[Instances]):
-        """Ground truths of a batch as [N,K,4] boxes, [N,K] classes and [N] counts (K = the batch maximum, >= 1)."""
+        """Ground truths of a batch as [N,K,4] boxes, [N,K] classes and [N] counts (K = the batch maximum, >= 1), on
+        the device.  Nothing here makes the host wait for the GPU: host-side data goes through pinned staging memory
+        and asynchronous copies (a ``torch.tensor(..., device=...)`` from pageable memory returns only when the stream
+        has drained, which would stop the host from queueing the next step while this one runs)."""
         dev = self.device
         lens = [len(g) for g in gt_instances]
         N, K = len(lens), max(max(lens), 1)
+        total = sum(lens)
+
+        def upload(t: torch.Tensor) -> torch.Tensor:
+            return t.pin_memory().to(dev, non_blocking=True)
+
+        counts = upload(torch.tensor(lens, dtype=torch.int32))
+        if all(g.gt_boxes.tensor.device.type == "cpu" for g in gt_instances):
+            # a loader's instances (host tensors): pad on the host, two uploads for the whole batch
+            boxes = torch.zeros(N, K, 4)
+            classes = torch.zeros(N, K, dtype=torch.int64)
+            for n, g in enumerate(gt_instances):
+                boxes[n, :lens[n]] = g.gt_boxes.tensor
+                classes[n, :lens[n]] = g.gt_classes
+            return upload(boxes), upload(classes), counts
         boxes = torch.zeros(N, K, 4, device=dev)
         classes = torch.zeros(N, K, dtype=torch.int64, device=dev)
-        if sum(lens):  # one scatter for the whole batch instead of slice copies per image
-            n_of = torch.tensor([n for n, k in enumerate(lens) for _ in range(k)], device=dev)
-            k_of = torch.tensor([j for k in lens for j in range(k)], device=dev)
-            boxes[n_of, k_of] = torch.cat([g.gt_boxes.tensor for g in gt_instances]).to(boxes.dtype)
-            classes[n_of, k_of] = torch.cat([g.gt_classes for g in gt_instances])
-        return boxes, classes, torch.tensor(lens, dtype=torch.int32, device=dev)
+        if total:  # one scatter for the whole batch instead of slice copies per image
+            idx = torch.empty(2, total, dtype=torch.int64)
+            o = 0
+            for n, k in enumerate(lens):
+                idx[0, o:o + k] = n
+                idx[1, o:o + k] = torch.arange(k)
+                o += k
+            idx = upload(idx)
+            boxes[idx[0], idx[1]] = torch.cat([g.gt_boxes.tensor.to(dev) for g in gt_instances]).to(boxes.dtype)
+            classes[idx[0], idx[1]] = torch.cat([g.gt_classes.to(dev) for g in gt_instances])
+        return boxes, classes, counts
 
     def _fused_training_step(self, batch: torch.Tensor, gt_instances: List[Instances]) -> Dict[str, torch.Tensor]:
         """Forward plan -> one fused label-assignment + loss call on the raw head tensors; backward: the loss
