@@ -94,6 +94,7 @@ class Yolov3Engine:
         self._bstream = None
         self.branch_on_side_stream = os.environ.get("YOLO_BRANCH_STREAM", "1") != "0"
         self.nms_on_side_stream = os.environ.get("YOLO_NMS_STREAM", "1") != "0"
+        self.decode_on_side_stream = os.environ.get("YOLO_DECODE_STREAM", "1") != "0"
         self.split_k = True  # few-pixel layers (small batches) split every tile's k loop over several workgroups
         # measurement hook: when a list, submit()/finish() append (label, start event, end event) recorded on the
         # stream the decode / NMS + gather launches run on
@@ -303,7 +304,7 @@ class Yolov3Engine:
         # the next batch's convolutions follow this batch's directly on the main stream.  The head tensors of this
         # slot are not written again before the main stream has waited for this slot's post-processing (finish()).
         main = torch.cuda.current_stream(self.device)
-        dstream = self._decode_stream() if self.nms_on_side_stream else main
+        dstream = self._decode_stream() if (self.nms_on_side_stream and self.decode_on_side_stream) else main
         if dstream is not main:
             dstream.wait_stream(main)
         with torch.cuda.stream(dstream):
