@@ -311,6 +311,32 @@ def test_fused_loss_kernels_match_the_torch_ops(cuda, case):
             assert float(d.buf[:, 0].min()) == 7.0   # the halo is not written
 
 
+def test_padded_targets_from_host_and_device_instances_agree(cuda):
+    """A loader hands over host tensors (the reference moves them with Instances.to(device), yolo.py:105), the
+    synthetic benchmarks device tensors: both routes give the same padded [N,K,4] boxes, [N,K] classes and counts,
+    an image without ground truth included; a batch without any box gives K = 1 rows of zeros."""
+    from yolo_amd.structures import Boxes, Instances
+    model, cfg = workload.build_model(config="yolov3.yaml", dtype="f32")
+    g = torch.Generator().manual_seed(3)
+    host = []
+    for k in (3, 0, 7, 1):
+        b = torch.rand(k, 4, generator=g) * 90
+        host.append(Instances((96, 96), gt_boxes=Boxes(b), gt_classes=torch.randint(0, 20, (k,), generator=g)))
+    dev = [i.to(cuda) for i in host]
+    bh, ch, nh = model._padded_targets(host)
+    bd, cd, nd = model._padded_targets(dev)
+    torch.cuda.synchronize()
+    assert bh.device.type == "cuda" and bh.shape == (4, 7, 4) and ch.shape == (4, 7) and nh.tolist() == [3, 0, 7, 1]
+    assert torch.equal(bh, bd) and torch.equal(ch, cd) and torch.equal(nh, nd)
+    for n, inst in enumerate(host):
+        k = len(inst)
+        assert torch.equal(bh[n, :k].cpu(), inst.gt_boxes.tensor) and float(bh[n, k:].abs().sum()) == 0.0
+        assert torch.equal(ch[n, :k].cpu(), inst.gt_classes)
+    empty = [Instances((96, 96), gt_boxes=Boxes(torch.zeros(0, 4)), gt_classes=torch.zeros(0, dtype=torch.int64))] * 2
+    b0, c0, n0 = model._padded_targets(empty)
+    assert b0.shape == (2, 1, 4) and n0.tolist() == [0, 0] and float(b0.abs().sum()) == 0.0
+
+
 def test_fused_step_equals_the_torch_op_step(cuda):
     """The model's default training step (fused loss) against the same model with fused_loss off: same losses and
     the same parameter gradients (f32 plan, so only the loss arithmetic differs)."""
