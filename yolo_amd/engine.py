@@ -359,10 +359,11 @@ class Yolov3Engine:
             n_det.record_stream(main)
         return det, n_det
 
-    def grow_candidates(self, h: "InFlight") -> bool:
+    def grow_candidates(self, h: "InFlight", total: Optional[int] = None) -> bool:
         """After a batch: if it produced more candidates than its buffers hold, enlarge the plan's buffers (for the
-        next run) and return True -- the caller runs the batch again.  Waits for the batch's decode."""
-        over = self.overflowed(h)
+        next run) and return True -- the caller runs the batch again.  ``total``: the batch's candidate count
+        (``img_offsets[N]``) if the caller has read it already; otherwise it is read here, which waits for the decode."""
+        over = self.overflowed(h) if total is None else max(0, int(total) - h.cand.scores.numel())
         if over:
             h.plan.cand_cap = int((h.cand.scores.numel() + over) * 1.25) + 1024
         return over > 0

@@ -100,6 +100,7 @@ class DarkNetFPN(Backbone):
         self.head_dtype = torch.float32
         self._engine = None
         self._engine_key = None
+        self._flat_tensors = None
         self._train_engine = None
         self.freeze_at = 0
 
@@ -116,8 +117,7 @@ class DarkNetFPN(Backbone):
     # ---- fused execution -------------------------------------------------------------------
     def engine(self):
         from ...engine import Yolov3Engine
-        key = (self.compute_dtype, self.head_dtype, next(self.parameters()).device,
-               tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
+        key = (self.compute_dtype, self.head_dtype) + self._weights_signature()
         if self._engine is None or self._engine_key != key:
             if self._num_classes is None:
                 raise RuntimeError("DarkNetFPN was built without num_classes / anchors; use "
@@ -128,6 +128,21 @@ class DarkNetFPN(Backbone):
                                         blocks=self.bottom_up.blocks_per_stage)
             self._engine_key = key
         return self._engine
+
+    def _weights_signature(self):
+        """(device, versions of every parameter and buffer): changes whenever a weight is updated in place (optimizer
+        step, load_state_dict), moved (module.to: new storage) or replaced (a new Parameter assigned to a module) --
+        what the packed, BatchNorm-folded copies of the engine depend on.  Walking the module tree costs ~0.3 ms, a
+        quarter of a single-image call, so the flat list of (owning dict, name, tensor) is kept and only checked:
+        identity of every entry, then its version counter and storage address."""
+        flat = self._flat_tensors
+        if flat is None or any(d.get(n) is not t for d, n, t in flat):
+            flat = []
+            for m in self.modules():
+                flat += [(m._parameters, n, t) for n, t in m._parameters.items() if t is not None]
+                flat += [(m._buffers, n, t) for n, t in m._buffers.items() if t is not None]
+            self._flat_tensors = flat
+        return (flat[0][2].device, tuple(t._version for _, _, t in flat), tuple(t.data_ptr() for _, _, t in flat))
 
     def train_engine(self):
         from ...train_engine import TrainEngine

@@ -105,6 +105,7 @@ class YOLOV3(nn.Module):
         self.obj_weight, self.noobj_weight = 1, 100
         self.fused_loss = True     # training: label assignment + losses as HIP kernels (False: the torch ops below)
         self._anchor_cache: Dict = {}
+        self._size_cache: Dict = {}
         self.matcher_threshold = cfg.MODEL.MATCHER.IGNORE_THRESHOLD
         self.matcher_labels = list(cfg.MODEL.MATCHER.LABELS)
         self.anchor_matcher = Matcher(threshold=self.matcher_threshold, labels=self.matcher_labels,
@@ -136,7 +137,8 @@ class YOLOV3(nn.Module):
         dev = self.device
         if all(s == sizes[0] for s in sizes):
             dt = torch.uint8 if all(i.dtype == torch.uint8 for i in imgs) else torch.float32
-            batch = torch.stack([i.to(device=dev, dtype=dt, non_blocking=True) for i in imgs])
+            ts = [i.to(device=dev, dtype=dt, non_blocking=True) for i in imgs]
+            batch = ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)   # one image: a view, no copy
         else:
             Hm, Wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
             batch = self.pixel_mean.view(1, -1, 1, 1).expand(len(imgs), -1, Hm, Wm).contiguous().float()
@@ -180,6 +182,8 @@ class YOLOV3(nn.Module):
         total = sum(lens)
 
         def upload(t: torch.Tensor) -> torch.Tensor:
+            if dev.type != "cuda":   # the label-assignment restatement also runs on a CPU model (tests)
+                return t
             return t.pin_memory().to(dev, non_blocking=True)
 
         counts = upload(torch.tensor(lens, dtype=torch.int32))
@@ -339,28 +343,44 @@ class YOLOV3(nn.Module):
         if self.device.type != "cuda":
             raise RuntimeError("yolo_amd runs on MI355X only (MODEL.DEVICE must be 'cuda'); there is no CPU fallback")
         batch, sizes = self._batch_images(batched_inputs)
-        dev = self.device
-        in_hw = torch.tensor(sizes, dtype=torch.int32, device=dev)
         out = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
-        out_hw = torch.tensor(out, dtype=torch.int32, device=dev)
+        in_hw, out_hw = self._size_tensors(tuple(sizes), tuple(out))
         eng = self.backbone.engine()
+        N = len(sizes)
         for _ in range(2):
             det, n_det = eng.detect(
                 batch, score_thr=self.test_score_thresh, nms_thr=self.test_nms_thresh, mean=self._mean, std=self._std,
                 max_det=self.max_detections_pre_image, nms_mode=self.nms_mode, auto_limit=self.nms_auto_numel,
                 in_hw=in_hw, out_hw=out_hw)
-            # rare (thousands of candidates per image, e.g. a very low threshold): the candidate buffers were too
-            # small and the tail of the candidates was dropped -- run the batch again with larger ones
-            if not eng.grow_candidates(eng.last_in_flight):
+            # ONE read-back per call: the per-image detection counts and, behind them, the number of candidates the
+            # decode produced.  Rare (thousands of candidates per image, e.g. a very low threshold): the candidate
+            # buffers were too small and the tail of the candidates was dropped -- run the batch again with larger ones
+            h = eng.last_in_flight
+            counts = torch.cat([n_det, h.cand.img_offsets[N:N + 1]]).tolist()
+            if not eng.grow_candidates(h, total=counts[N]):
                 break
-        n_det = n_det.tolist()
+        n_det = counts[:N]
+        boxes = det[..., :4].contiguous()      # three conversions for the whole batch, then views per image
+        scores = det[..., 4].contiguous()
+        classes = det[..., 5].to(torch.int64)
         results = []
         for n, (oh, ow) in enumerate(out):
-            d = det[n, :n_det[n]]
-            inst = Instances((oh, ow), pred_boxes=Boxes(d[:, :4].clone()), scores=d[:, 4].clone(),
-                             pred_classes=d[:, 5].to(torch.int64))
+            k = n_det[n]
+            inst = Instances((oh, ow), pred_boxes=Boxes(boxes[n, :k]), scores=scores[n, :k], pred_classes=classes[n, :k])
             results.append({"instances": inst})
         return results
+
+    def _size_tensors(self, sizes, out):
+        """[N, 2] int32 device tensors of the stored and of the requested output sizes; kept for the size
+        combinations seen last (a serving loop repeats them), so that a call uploads nothing."""
+        key = (sizes, out)
+        hit = self._size_cache.get(key)
+        if hit is None:
+            if len(self._size_cache) >= 64:
+                self._size_cache.pop(next(iter(self._size_cache)))
+            both = torch.tensor([sizes, out], dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+            hit = self._size_cache[key] = (both[0], both[1])
+        return hit
 
 
 def _build(cfg):
