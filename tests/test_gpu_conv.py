@@ -313,7 +313,7 @@ def test_resblock_c64_fused(cuda, geom):
 # several workgroups (single-image inference)
 SPLITK_SHAPES = [(512, 1024, 3, 1, 1, 13, 13, True, False), (256, 512, 3, 1, 1, 26, 26, True, False),
                  (1024, 512, 1, 1, 1, 13, 13, False, False), (128, 256, 3, 1, 1, 52, 52, False, False),
-                 (512, 256, 1, 1, 2, 13, 13, False, True), (1024, 255, 1, 1, 1, 13, 13, False, False),
+                 (768, 256, 1, 1, 2, 13, 13, False, True), (1024, 255, 1, 1, 1, 13, 13, False, False),
                  (256, 512, 3, 2, 1, 52, 52, False, False), (768, 256, 1, 1, 1, 26, 26, False, False)]
 
 

@@ -1145,17 +1145,34 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const SplitRedu
 }
 
 // Split-K pays when a layer has too few tiles to occupy the chip and a long k loop: batch 1 (16-58 tiles of 96-192
-// pixels for 256 CUs, 18-72 k-steps each).  splits = how many workgroups share one tile's k range.
+// pixels for 256 CUs, 18-72 k-steps each).  splits = how many workgroups share one tile's k range.  Every split layer
+// costs a second launch (the slab sum, ~5 us with its dependency gap), so the rule is tuned on the whole single-image
+// pass (interleaved A/B of library builds, tools/ab_latency_libs.sh): layers of fewer than 12 k-steps stay whole
+// (1x1 with 512 input channels: the halved loop saves less than the extra launch costs), ONE workgroup per CU (256
+// slots: a workgroup alone on its CU runs its k-steps 1.3 x faster than two sharing it), at least six k-steps per
+// workgroup, at most eight slabs to sum: 1.12 -> 1.03 ms per image, batch 4 1.50 -> 1.37 ms.
+#ifndef YOLO_SPLITK_MIN_STEPS
+#define YOLO_SPLITK_MIN_STEPS 12
+#endif
+#ifndef YOLO_SPLITK_SLOTS
+#define YOLO_SPLITK_SLOTS 256
+#endif
+#ifndef YOLO_SPLITK_MIN_PER
+#define YOLO_SPLITK_MIN_PER 6
+#endif
+#ifndef YOLO_SPLITK_MAX
+#define YOLO_SPLITK_MAX 8
+#endif
 static int splitk_choice(int M, int Cin, int Cout, int k, int dtype, int* tp_out) {
     if (dtype != YOLO_BF16 || Cin % 64 != 0 || Cout <= 64) return 1;
     const int nsteps = conv_nsteps(Cin, k, dtype);
     const int n_ctiles = (Cout + 127) / 128;
     const int tp = M <= 96 * 4 ? 96 : 128;  // few pixels: the smaller tile wastes less of its last tile
     const int tiles = ((M + tp - 1) / tp) * n_ctiles;
-    if (tiles >= 128 || nsteps < 8) return 1;  // (a quarter of the resident slots: below it the chip is mostly idle)
-    int splits = 512 / tiles;             // fill the 512 resident workgroup slots once
-    if (splits > nsteps / 4) splits = nsteps / 4;  // at least four k-steps per workgroup
-    if (splits > 16) splits = 16;
+    if (tiles >= 128 || nsteps < YOLO_SPLITK_MIN_STEPS) return 1;  // (a quarter of the resident slots: below it the chip is mostly idle)
+    int splits = YOLO_SPLITK_SLOTS / tiles;             // fill the chip's workgroup slots once
+    if (splits > nsteps / YOLO_SPLITK_MIN_PER) splits = nsteps / YOLO_SPLITK_MIN_PER;  // k-steps per workgroup
+    if (splits > YOLO_SPLITK_MAX) splits = YOLO_SPLITK_MAX;
     *tp_out = tp;
     return splits < 2 ? 1 : splits;
 }
