@@ -2,7 +2,7 @@
 batch 1 (and a few small batches), 416 x 416, bf16, with and without split-K convolutions, interleaved in one process.
 (Replaying the pass from a captured HIP graph was measured too: 1.14 ms against 1.12 ms eager at batch 1 -- the pass is
 bound by its ~125 dependent kernels, not by the host -- so no graph path is kept.)
-usage: python tools/latency_bench.py [reps]"""
+usage: python tools/latency_bench.py [reps] [batches, e.g. 1,4,16]"""
 import json
 import statistics
 import sys
@@ -20,7 +20,8 @@ def main():
     eng = model.backbone.engine()
     kw = dict(score_thr=cfg.MODEL.YOLOV3.TEST_SCORE_THRESH, nms_thr=cfg.MODEL.YOLOV3.TEST_NMS_THRESH,
               mean=cfg.MODEL.PIXEL_MEAN, std=cfg.MODEL.PIXEL_STD)
-    for batch in (1, 4, 16):
+    batches = tuple(int(b) for b in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 4, 16)
+    for batch in batches:
         imgs = workload.synthetic_images(batch, 416, 416, seed=1, device=model.device)
         row = dict(batch=batch)
         dets = {}
