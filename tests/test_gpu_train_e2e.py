@@ -581,6 +581,84 @@ def test_multi_scale_training_80_classes(cuda):
     model.eval()
 
 
+def test_training_trajectory_fp32_follows_the_oracle(cuda):
+    """Four whole iterations of the loop -- forward, backward, SGD with momentum and the two weight-decay groups, the
+    warm-up schedule, BatchNorm running statistics carried from step to step -- next to the oracle's autograd driven by
+    torch.optim.SGD on the CPU.  Training this randomly initialised network is CHAOTIC: the oracle run in float64
+    instead of float32, or with its weights perturbed by 1e-6, already differs by 30 % in the regression loss of the
+    third step, and its four-step parameter update has a cosine of only 0.77-0.79 with the unperturbed one (norm ratio
+    1.01).  What a step hands to the next is therefore checked on the quantities that stay smooth: the first step's
+    losses exactly (1e-4: nothing has diverged yet), the second step's within 6 % (one update with the warm-up's first
+    learning rate lies between them; a 1e-6 perturbation of the oracle moves its regression loss there by 4 %), the dominant objectness loss of every step within 3 %, the NORM of the
+    four-step update within 5 % of the oracle's -- a missing warm-up, a wrong momentum or a decayed normalisation
+    group change it by tens of per cent -- with a cosine above 0.6, and the running statistics (5e-3 for the first
+    trainable layer, 10 % deep in the network)."""
+    from oracle import yolo_train_ref as T
+    from yolo_amd.structures import Boxes, Instances
+    from yolo_amd.trainer import Trainer
+    N, S, base_lr, warm_iters, warm_factor, steps = 4, 160, 0.0005, 2, 0.5, 4
+    model, cfg = workload.build_model(config="yolov3.yaml", dtype="f32",
+                                      opts=["OUTPUT_DIR", "", "SOLVER.CHECKPOINT_PERIOD", 0, "SOLVER.BASE_LR", base_lr,
+                                            "SOLVER.WARMUP_ITERS", warm_iters, "SOLVER.WARMUP_FACTOR", warm_factor])
+    C = cfg.MODEL.YOLOV3.NUM_CLASSES
+    imgs = workload.synthetic_images(N, S, S, seed=3)
+    gb, gc = T.synthetic_targets(N, S, C, seed=11, max_boxes=5)
+    inputs = [dict(image=im, instances=Instances((S, S), gt_boxes=Boxes(b), gt_classes=c)) for im, b, c in zip(imgs, gb, gc)]
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # ---- oracle: autograd + torch.optim.SGD with the reference's groups (detectron2 build_optimizer: no decay on norms)
+    frozen = set(T.frozen_names(2))
+    layer_of = lambda k: k.rsplit(".norm.", 1)[0].rsplit(".weight", 1)[0].rsplit(".bias", 1)[0]  # noqa: E731
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and "running" not in k and layer_of(k) not in frozen}
+    opt = torch.optim.SGD([dict(params=[p for k, p in params.items() if ".norm." not in k], weight_decay=cfg.SOLVER.WEIGHT_DECAY),
+                           dict(params=[p for k, p in params.items() if ".norm." in k], weight_decay=cfg.SOLVER.WEIGHT_DECAY_NORM)],
+                          lr=base_lr, momentum=cfg.SOLVER.MOMENTUM)
+    state = dict(sd)
+    want = []
+    for it in range(steps):
+        alpha = min(it / warm_iters, 1.0)
+        for g in opt.param_groups:
+            g["lr"] = base_lr * (warm_factor * (1 - alpha) + alpha if it < warm_iters else 1.0)
+        full = dict(state)
+        full.update(params)
+        stats = {}
+        losses = T.forward_training(imgs.float() / 255.0, full, gb, gc, C, freeze_at=2, stats=stats)
+        opt.zero_grad()
+        sum(losses.values()).backward()
+        opt.step()
+        for name, (rm, rv) in stats.items():
+            state[name + ".norm.running_mean"], state[name + ".norm.running_var"] = rm, rv
+        want.append({k: float(v.detach()) for k, v in losses.items()})
+    # ---- the HIP path, through the Trainer
+    tr = Trainer(cfg, model, iter(lambda: inputs, None), log=lambda m: None)
+    got = [{k: float(v) for k, v in tr.run_step().items()} for _ in range(steps)]
+    torch.cuda.synchronize()
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-6)  # noqa: E731
+    for k in want[0]:
+        assert rel(got[0][k], want[0][k]) < 1e-4, (0, k, got[0][k], want[0][k])
+        assert rel(got[1][k], want[1][k]) < 6e-2, (1, k, got[1][k], want[1][k])
+    for it in range(steps):
+        assert rel(got[it]["confs_loss"], want[it]["confs_loss"]) < 3e-2, (it, got[it], want[it])
+    assert want[-1]["confs_loss"] < 0.7 * want[0]["confs_loss"]   # the steps did move the model
+    live = dict(model.named_parameters())
+    for sel in (lambda k: True, lambda k: ".norm." in k, lambda k: ".norm." not in k):
+        d_got = torch.cat([(live[k].detach().float().cpu() - sd[k]).flatten() for k in params if sel(k)]).double()
+        d_ref = torch.cat([(p.detach() - sd[k]).flatten() for k, p in params.items() if sel(k)]).double()
+        cos = float(F.cosine_similarity(d_got, d_ref, dim=0))
+        ratio = float(d_got.norm() / d_ref.norm())
+        assert cos > 0.6 and 0.95 < ratio < 1.05, (cos, ratio)
+    bufs = dict(model.named_buffers())
+    # the first trainable layer sees the frozen prefix's output: its statistics only feel its own weights' drift; deep
+    # layers feel everyone's
+    for name, tol in (("backbone.bottom_up.res2.0.downsample", 5e-3), ("backbone.bottom_up.res3.2.conv2", 0.1),
+                      ("backbone.fpn_lateral0.blocks.0", 0.1), ("backbone.fpn_output2.conv", 0.1)):
+        var = state[name + ".norm.running_var"]
+        assert _l2(bufs[name + ".norm.running_var"].cpu(), var) < tol, name
+        # means are differences of large terms: measured against the channel's standard deviation
+        dm = (bufs[name + ".norm.running_mean"].cpu() - state[name + ".norm.running_mean"]).abs() / var.sqrt()
+        assert float(dm.max()) < 4 * tol, (name, float(dm.max()))
+
+
 def test_training_fits_a_structured_set_and_the_inference_path_finds_it(cuda):
     """The whole loop as a user runs it (reference tools/train_net.py -> DefaultTrainer.run_step, then the model in eval
     mode): 400 SGD steps in bf16 on 32 synthetic images with real structure (filled rectangles, class = colour) must
