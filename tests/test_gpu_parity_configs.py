@@ -32,7 +32,7 @@ pytestmark = pytest.mark.gpu
 MARGIN = 0.02
 
 
-from oracle.compare import matched_fraction  # noqa: E402
+from oracle.compare import matched_fraction, rows_of  # noqa: E402
 
 
 def _as_rows(inst):
@@ -177,3 +177,55 @@ def test_detector_end_to_end_bf16(cuda):
     print(f"bf16 detections recovering the fp32 oracle's (IoU > 0.5, score within 0.1): HIP {ours:.3f}, "
           f"the oracle's own bf16 restatement {own:.3f} ({n_ref} detections)")
     assert ours >= own - 0.1, (ours, own)  # (3)
+
+
+def test_chained_bf16_meets_5e_2_on_trained_weights(cuda):
+    """north_star's bf16 tolerance (conv / head outputs within 5e-2 of the fp32 reference) on the WHOLE chained network,
+    in the regime the tolerance is meant for: trained weights.  The network is first fitted to the structured synthetic
+    set (tools/overfit_check.py: 400 bf16 SGD steps through the HIP training path), then its bf16 inference plan is
+    compared with the fp32 oracle on the trained state dict: every stage output and head tensor within 5e-2 max-norm
+    (measured 0.3e-2 .. 1.7e-2, the same as the oracle's own bf16 restatement -- against 0.10 .. 0.18 on the randomly
+    initialised network, where each stage doubles a perturbation).  And at detection level, with the review's
+    tolerances: at least 95 % of the fp32 oracle's detections above thr + 0.02 have a bf16 twin of the same class at
+    IoU > 0.9 with a score within 0.02."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import overfit_check
+    from oracle import nms_c, yolo_ref as R
+    res, model, data = overfit_check.run(steps=400, n_images=32, side=256, dtype="bf16", log=lambda m: None,
+                                         return_model=True)
+    assert res["recall_after"] >= 0.8, res
+    model.eval()
+    cfg_thr, cfg_nms = model.test_score_thresh, model.test_nms_thresh
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    imgs = torch.stack([d["image"] for d in data[:4]]).cpu()
+    x = imgs.float() / 255.0
+    taps32 = {}
+    with torch.no_grad():
+        ref32 = R.fpn_forward(x, sd, taps=taps32)
+    model.backbone.compute_dtype = torch.bfloat16
+    out = model.backbone(x.to(cuda))
+    torch.cuda.synchronize()
+    plan = model.backbone.engine().plan(4, 256, 256)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())  # noqa: E731
+    worst = {}
+    for name in ("res3", "res4", "res5"):
+        worst[name] = rel(plan.taps[name].nchw().float().cpu(), taps32[name])
+    for name in ("p3", "p4", "p5"):
+        worst[name] = rel(out[name].float().cpu(), ref32[name])
+    print("bf16 plan against the fp32 oracle on trained weights:", {k: round(v, 4) for k, v in worst.items()})
+    assert max(worst.values()) < 5e-2, worst
+    # detections: bf16 HIP path against the fp32 oracle's inference()
+    got = [_as_rows(r["instances"]) for r in model([dict(image=i) for i in imgs])]
+    with torch.no_grad():
+        want = R.inference([i.float() for i in imgs], sd, model.num_classes, cfg_thr, cfg_nms, nms_fn=nms_c.nms,
+                           device_kind="gpu")
+    n_ref, hit = 0, 0.0
+    for g, (rb, rs, rc) in zip(got, want):
+        w = rows_of(rb, rs, rc)
+        f, n = matched_fraction(w, g, cfg_thr + 0.02, 0.9, 0.02)
+        hit += f * n
+        n_ref += n
+    assert n_ref >= 6, n_ref
+    assert hit / n_ref >= 0.95, (hit, n_ref)

@@ -65,7 +65,7 @@ def recall(model, data, batch):
     return hit / max(total, 1), dets / len(data)
 
 
-def run(steps=400, n_images=32, side=256, dtype="bf16", batch=16, lr=0.01, log=print):
+def run(steps=400, n_images=32, side=256, dtype="bf16", batch=16, lr=0.01, log=print, return_model=False):
     model, cfg = workload.build_model(config="yolov3.yaml", dtype=dtype, device="cuda:0",
                                       opts=["OUTPUT_DIR", "", "SOLVER.CHECKPOINT_PERIOD", 0, "SOLVER.BASE_LR", lr,
                                             "SOLVER.WARMUP_ITERS", 50, "SOLVER.MAX_ITER", steps, "SOLVER.STEPS", (steps,)])
@@ -95,7 +95,7 @@ def run(steps=400, n_images=32, side=256, dtype="bf16", batch=16, lr=0.01, log=p
                loss_first=round(first, 4), loss_last=round(last, 4), recall_before=round(r0, 3), recall_after=round(r1, 3),
                detections_per_image_after=round(per_image, 2))
     log(json.dumps(res))
-    return res
+    return (res, model, data) if return_model else res
 
 
 if __name__ == "__main__":
