@@ -674,3 +674,21 @@ def test_training_fits_a_structured_set_and_the_inference_path_finds_it(cuda):
     assert res["loss_last"] < res["loss_first"] / 100, res
     assert res["recall_after"] >= 0.8, res
     assert res["detections_per_image_after"] < 20, res
+
+
+def test_bf16_gradients_match_the_fp32_oracle_on_trained_weights(cuda):
+    """The bf16 training plan against the fp32 oracle's autograd DIRECTLY -- possible once the weights are trained (on
+    the randomly initialised network a bf16 forward already differs by 1-25 % at the heads, which is why the other
+    bf16 tests compare with torch autograd on the plan's own tensors): after 400 steps on the structured synthetic
+    set, one forward / backward on fresh images of the same kind gives losses within 1e-2 of the oracle's and, for
+    each of the 210 trainable tensors, a gradient with cosine > 0.95 to the oracle's (measured: minimum 0.988, median
+    0.9965; all gradients as one vector: cosine 0.996, norm ratio 1.001)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import trained_bf16_grads
+    out = trained_bf16_grads.compare(steps=400, log=lambda m: None)
+    for k, v in out["losses_oracle"].items():
+        assert abs(out["losses_hip"][k] - v) <= 1e-2 * abs(v), (k, out)
+    assert out["tensors"] == 210
+    assert out["cos_min"] > 0.95 and out["cos_all"] > 0.99 and 0.98 < out["norm_ratio_all"] < 1.02, out
