@@ -320,3 +320,31 @@ def test_single_image_split_k_equals_the_plain_plan(cuda, calibrated):
     # the head logits move by bf16 roundings of intermediate layers: scores agree to a few hundredths
     assert float((a[0][0, :k, 4] - b[0][0, :k, 4]).abs().median()) < 2e-2
     model.backbone.compute_dtype = torch.float32
+
+
+def test_engine_follows_weight_changes(cuda):
+    """The inference engine holds packed, BatchNorm-folded copies of the weights and is rebuilt when they change: the
+    same engine object while nothing changes, a new one (and new results) after an in-place update
+    (load_state_dict / optimizer-style), after a Parameter object is replaced, and after a running statistic is
+    overwritten -- checked through a kept flat list of the tensors rather than a walk of the module tree per call."""
+    model, cfg = workload.calibrated_model(size=128, calib_batch=2, config="yolov3.yaml", dtype="f32")
+    bb = model.backbone
+    x = (workload.synthetic_images(1, 64, 64, seed=3).float() / 255.0).to(cuda)
+    e0 = bb.engine()
+    assert bb.engine() is e0
+    y0 = bb(x)["p5"].clone()
+    conv = bb.fpn_lateral0.blocks[0]
+    with torch.no_grad():
+        conv.weight.mul_(1.5)                       # in place: the version counter moves
+    e1 = bb.engine()
+    assert e1 is not e0
+    y1 = bb(x)["p5"].clone()
+    assert float((y1 - y0).abs().max()) > 0
+    conv.weight = torch.nn.Parameter(conv.weight.detach() / 1.5)   # a new Parameter object with the old values
+    e2 = bb.engine()
+    assert e2 is not e1
+    y2 = bb(x)["p5"].clone()
+    assert float((y2 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    conv.norm.running_var.copy_(conv.norm.running_var * 4.0)       # a buffer, in place
+    assert bb.engine() is not e2
+    assert float((bb(x)["p5"] - y0).abs().max()) > 0

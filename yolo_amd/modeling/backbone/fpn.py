@@ -130,19 +130,26 @@ class DarkNetFPN(Backbone):
         return self._engine
 
     def _weights_signature(self):
-        """(device, versions of every parameter and buffer): changes whenever a weight is updated in place (optimizer
-        step, load_state_dict), moved (module.to: new storage) or replaced (a new Parameter assigned to a module) --
-        what the packed, BatchNorm-folded copies of the engine depend on.  Walking the module tree costs ~0.3 ms, a
-        quarter of a single-image call, so the flat list of (owning dict, name, tensor) is kept and only checked:
-        identity of every entry, then its version counter and storage address."""
-        flat = self._flat_tensors
-        if flat is None or any(d.get(n) is not t for d, n, t in flat):
-            flat = []
+        """(device, versions and storage addresses of every parameter and buffer): changes whenever a weight is updated
+        in place (optimizer step, load_state_dict), moved (module.to: new storage) or replaced (a new Parameter or
+        buffer assigned to a module, also where there was none) -- what the packed, BatchNorm-folded copies of the
+        engine depend on.  Walking the module tree costs ~0.3 ms, a quarter of a single-image call, so the flat list of
+        (owning dict, name, tensor) is kept and only checked: the size of every module's parameter and buffer dicts,
+        the identity of every entry, then version counter and storage address of the tensors."""
+        kept = self._flat_tensors
+        if kept is not None:
+            flat, sizes = kept
+            if any(len(d) != n for d, n in sizes) or any(d.get(k) is not t for d, k, t in flat):
+                kept = None
+        if kept is None:
+            flat, sizes = [], []
             for m in self.modules():
-                flat += [(m._parameters, n, t) for n, t in m._parameters.items() if t is not None]
-                flat += [(m._buffers, n, t) for n, t in m._buffers.items() if t is not None]
-            self._flat_tensors = flat
-        return (flat[0][2].device, tuple(t._version for _, _, t in flat), tuple(t.data_ptr() for _, _, t in flat))
+                for d in (m._parameters, m._buffers):
+                    sizes.append((d, len(d)))
+                    flat += [(d, k, t) for k, t in d.items()]
+            kept = self._flat_tensors = (flat, sizes)
+        live = [t for _, _, t in kept[0] if t is not None]
+        return (live[0].device, tuple(t._version for t in live), tuple(t.data_ptr() for t in live))
 
     def train_engine(self):
         from ...train_engine import TrainEngine
