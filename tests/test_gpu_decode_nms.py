@@ -215,6 +215,52 @@ def test_nms_clustered_deep_chains(cuda):
             assert torch.equal(g, _oracle(p, 0.5, mode))
 
 
+def test_nms_top_k_with_short_class_segments(cuda):
+    """top_k > 0 with every class segment of an image short enough for one wave to sort it (the form the model's
+    inference uses): images are sorted by class only, every segment is put into score order by its sweep wave, and the
+    image's first top_k detections come from a merge of the segments' kept lists.  Bit-exact against the oracle's first
+    top_k, with: scores quantised to 33 levels (equal keys inside and across segments; torch's order on equal scores is
+    the candidate index), boxes spread out (long kept lists) and clustered (short ones: segments run out during the
+    merge), top_k of 1 / a few / more than survive, images that do NOT qualify (a class with more than 512
+    candidates, at most 512 candidates in all, none) in the same batch, and the coordinate-trick mode."""
+    from yolo_amd import ops
+    g = torch.Generator().manual_seed(5)
+
+    def quantised(p, levels=32):
+        b, s, c = p
+        return b, torch.round(s * levels) / levels, c
+
+    def spread(p, f):
+        return p[0] * f, p[1], p[2]
+
+    tied = quantised(spread(util.stress_boxes(6000, 11, num_classes=20), 4.0))
+    tied_few = quantised(util.stress_boxes(3000, 12, num_classes=80), levels=4)
+    plain = util.stress_boxes(9000, 13, num_classes=80)
+    long_class = util.stress_boxes(3000, 14, num_classes=2)       # 1500 per class: not sorted by a wave
+    small = util.stress_boxes(300, 15, num_classes=20)            # the counting path
+    empty = (torch.empty(0, 4), torch.empty(0), torch.empty(0, dtype=torch.int64))
+    clustered = util.clustered_boxes(300, 76, 9)
+    clustered_small = util.clustered_boxes(150, 40, 10)
+    one_per_class = (torch.rand(600, 4, generator=g).cumsum(1) * 50, torch.rand(600, generator=g),
+                     torch.arange(600) % 80)
+    uneven = util.stress_boxes(5000, 16, num_classes=80)
+    uneven = (uneven[0], uneven[1], torch.where(torch.arange(5000) < 500, torch.zeros(5000, dtype=uneven[2].dtype),
+                                                uneven[2]))        # class 0 right at the limit and beyond
+    batch = [tied, long_class, plain, small, empty, clustered, tied_few, one_per_class, uneven, clustered_small]
+    for mode in (ops.NMS_PER_CLASS, ops.NMS_COORD_TRICK):
+        want = [_oracle(p, 0.5, mode) for p in batch]
+        for top_k in (1, 7, 100, 1000, 20000):
+            got = _run_nms(cuda, batch, 0.5, mode, top_k=top_k)
+            for i, (w, gk) in enumerate(zip(want, got)):
+                assert torch.equal(gk, w[:top_k]), (mode, top_k, i)
+    # a lower threshold (more suppression, shorter lists) and a higher one
+    for thr in (0.2, 0.8):
+        want = [_oracle(p, thr, 0) for p in batch]
+        got = _run_nms(cuda, batch, thr, 0, top_k=100)
+        for i, (w, gk) in enumerate(zip(want, got)):
+            assert torch.equal(gk, w[:100]), (thr, i)
+
+
 def test_nms_single_class_long_segment(cuda):
     """One class only: a 6000-box segment (kept list spills past the LDS list)."""
     b, s, c = util.stress_boxes(6000, 5, num_classes=1)

@@ -254,6 +254,13 @@ __device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* k
 }
 
 constexpr int SORT_SMALL = 1024;     // table size of the counting path (one entry per thread)
+constexpr int MERGE_MAX = 1024;     // offers per merge round in the emit kernel
+#ifndef NMS_MERGE_SHARE
+#define NMS_MERGE_SHARE 4            // offers per segment and round, in units of a segment's fair share of top_k (tunable)
+#endif
+constexpr int SEG_SORT_MAX = 512;    // (image, class) segments up to this size are put into score order by their sweeping wave
+// values of NmsParams::agnostic
+constexpr unsigned char IMG_PER_CLASS = 0, IMG_AGNOSTIC = 1, IMG_SEGMENT_SORTED = 2;
 constexpr int SORT_COUNT_MAX = 512;  // candidates per image up to which the orders are found by counting: its work
                                      // is quadratic (3 us at 200, 75 us at 1000; the radix passes take ~30 us)
 
@@ -308,9 +315,10 @@ __global__ void __launch_bounds__(SORT_THREADS) nms_sort_kernel(const NmsParams 
         }
     } else if (tid == 0) {
         agnostic_s = 0;
-        p.agnostic[n] = 0;
+        p.agnostic[n] = IMG_PER_CLASS;
     }
     if (tid == 0) seg_count = seg_next = 0;
+    __syncthreads();   // agnostic_s decides the path below for every thread
     // ---- few candidates (the usual case: a few hundred per image): both orders by counting.  Every thread owns one
     //      candidate and counts the candidates that precede it -- m broadcast reads of LDS per order, no passes, no
     //      scatter: the same two orders as the radix passes below (same keys, same tie-breaks), in a few microseconds.
@@ -371,9 +379,72 @@ __global__ void __launch_bounds__(SORT_THREADS) nms_sort_kernel(const NmsParams 
         if (head) p.seg_start[seg_base + atomicAdd(&seg_next, 1u)] = (unsigned)(b + tid);
         return;
     }
-    // ---- order B: stable sort by descending score (= by ascending index among equal scores)
     unsigned* kbuf[2] = {p.sort_k0 + b, p.sort_k1 + b};
     unsigned* vbuf[2] = {p.sort_v0 + b, p.sort_v1 + b};
+    // ---- top-k, per-class segments of moderate size: only the CLASS pass runs here (one stable pass: order A' = class,
+    //      then candidate index); each segment is put into score order by the wave that sweeps it, and the emit kernel
+    //      merges the segments' kept lists.  The four passes over the scores -- what a single workgroup per image spends
+    //      most of its time on when an image has tens of thousands of candidates -- are not needed for the first top_k.
+    if (p.top_k > 0 && p.cbits <= RADIX_BITS && agnostic_s == 0) {
+        for (int i0 = 0; i0 < m; i0 += SORT_TILE) {
+            unsigned cl[SORT_E];
+#pragma unroll
+            for (int e = 0; e < SORT_E; ++e) {
+                const int i = i0 + e * SORT_THREADS + tid;
+                cl[e] = (unsigned)p.classes[b + (i < m ? i : m - 1)];
+            }
+#pragma unroll
+            for (int e = 0; e < SORT_E; ++e) {
+                const int i = i0 + e * SORT_THREADS + tid;
+                if (i < m) kbuf[0][i] = cl[e];
+            }
+        }
+        __syncthreads();
+        radix_histograms(kbuf[0], m, 1, sh);   // the digit IS the class: hist[0][c] = size of segment c
+        __shared__ int seg_too_long;
+        if (tid == 0) seg_too_long = 0;
+        __syncthreads();
+        if (tid < RADIX_BINS && sh.hist[0][tid] > (unsigned)SEG_SORT_MAX) seg_too_long = 1;
+        __syncthreads();
+        if (seg_too_long == 0) {
+            const bool moved = radix_pass(kbuf[0], nullptr, kbuf[1], vbuf[1], m, 0, sh);
+            const unsigned* ck = moved ? kbuf[1] : kbuf[0];
+            const unsigned* cv = moved ? vbuf[1] : nullptr;   // candidate index inside the image (identity if nothing moved)
+            const unsigned nkey = (unsigned)n << p.cbits;
+            unsigned heads = 0;
+            for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
+#pragma unroll
+                for (int e = 0; e < SORT_E; ++e) {
+                    const int t = t0 + e * SORT_THREADS + tid;
+                    if (t < m) {
+                        const unsigned c = ck[t], cp = t > 0 ? ck[t - 1] : ~0u;
+                        p.keyA[b + t] = nkey | c;
+                        p.valA[b + t] = (unsigned)b + (cv ? cv[t] : (unsigned)t);   // the candidate itself (there is no order B)
+                        heads += cp != c ? 1u : 0u;
+                    }
+                }
+            }
+            if (heads) atomicAdd(&seg_count, heads);
+            __syncthreads();
+            if (tid == 0) seg_base = atomicAdd(p.nseg, seg_count);
+            __syncthreads();
+            for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
+#pragma unroll
+                for (int e = 0; e < SORT_E; ++e) {
+                    const int t = t0 + e * SORT_THREADS + tid;
+                    if (t < m && (t == 0 || ck[t - 1] != ck[t])) p.seg_start[seg_base + atomicAdd(&seg_next, 1u)] = (unsigned)(b + t);
+                }
+            }
+            __syncthreads();   // ck (possibly sort_k0) has been read for the last time
+            if (tid == 0) {
+                p.agnostic[n] = IMG_SEGMENT_SORTED;
+                p.sort_v0[b] = seg_base;       // this image's entries of seg_start: the emit kernel merges them
+                p.sort_v0[b + 1] = seg_count;
+            }
+            return;
+        }
+    }
+    // ---- order B: stable sort by descending score (= by ascending index among equal scores)
     for (int i0 = 0; i0 < m; i0 += SORT_TILE) {
         float sc[SORT_E];
 #pragma unroll
@@ -504,10 +575,41 @@ __device__ __forceinline__ f32x4 bcast_box(const f32x4 b, int srclane) {
     return r;
 }
 
+// Ranks of a segment's candidates by counting, for the wave that owns the segment.  skey[0 .. len4) holds the keys
+// (ascending key = descending score; padded to a multiple of 4 with 0xFFFFFFFF), lane l owns the candidates at
+// positions l + 64 q, q < NOWN, whose keys are mykey[q].  The order wanted is (key, position):
+//   rank_e = #{j : key_j < key_e} + #{j < e : key_j == key_e}.
+// Positions of another group of 64 than e's are all before or all behind e, so against those the test is ONE unsigned
+// compare, with key_e + 1 (groups before) or key_e (groups behind) as the bound.  e's own group is counted with key_e
+// as well, which leaves out equal keys at lower positions of the same group -- and with key 0xFFFFFFFF (no +1) equal
+// keys of earlier groups: in both cases the candidates concerned end with EQUAL ranks, which the caller detects.
+template <int NOWN>
+__device__ __forceinline__ void rank_by_counting(const unsigned* skey, int len4, const unsigned (&mykey)[SEG_SORT_MAX / 64],
+                                                 unsigned (&rank)[SEG_SORT_MAX / 64]) {
+    unsigned keyp1[NOWN];
+#pragma unroll
+    for (int q = 0; q < NOWN; ++q) keyp1[q] = mykey[q] == 0xFFFFFFFFu ? mykey[q] : mykey[q] + 1u;
+#pragma unroll
+    for (int c = 0; c < NOWN; ++c) {
+        const int jend = c == NOWN - 1 ? len4 - 64 * c : 64;
+#pragma unroll 2
+        for (int jj = 0; jj < jend; jj += 4) {
+            const u32x4 k = *(const u32x4*)(skey + 64 * c + jj);
+#pragma unroll
+            for (int q = 0; q < NOWN; ++q) {
+                const unsigned thr = c < q ? keyp1[q] : mykey[q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rank[q] += k[i] < thr ? 1u : 0u;
+            }
+        }
+    }
+}
+
 constexpr int KEPT_LDS = 448;  // kept boxes per wave held in LDS (7 KiB); the rest spills to global
 
 __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
     __shared__ f32x4 kept_lds[4][KEPT_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned seg_key[4][SEG_SORT_MAX + 4], seg_idx[4][SEG_SORT_MAX];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned nseg = *p.nseg;
@@ -521,24 +623,132 @@ __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
         const unsigned img_end = (unsigned)img_begin(p, n + 1);
         const int m_img = (int)img_end - img_begin(p, n);
         const bool trick = p.mode == YOLO_NMS_COORD_TRICK || (p.mode == YOLO_NMS_AUTO && 4ll * m_img <= p.auto_limit);
-        const bool agn = p.agnostic[n] != 0;  // the whole image is this one segment; every box shifts by its own class
+        const bool agn = p.agnostic[n] == IMG_AGNOSTIC;  // the whole image is this one segment; every box shifts by its own class
+        const bool seg_sorted = p.agnostic[n] == IMG_SEGMENT_SORTED;  // order A' (class, index): this wave sorts the segment by score
         // torchvision: offsets = idxs.to(boxes) * (max_coordinate + 1); boxes_for_nms = boxes + offsets
         const float unit = p.img_max[n] + 1.0f;
         float shift = trick ? (float)cls * unit : 0.0f;
         f32x4* kspill = p.kept_spill + start;
         int nkept = 0;
         const int kcap = p.top_k > 0 ? p.top_k : 0x7fffffff;
+        // ---- a segment in (class, index) order: this wave puts it into score order first.  Keys (descending score =
+        //      ascending key) and candidate indices go to LDS; every lane ranks its candidates by COUNTING the ones
+        //      that precede them (key, then position = candidate index: torch's stable order), reading the keys four
+        //      per LDS instruction as broadcasts; the candidates are then written back in rank order.
+        unsigned* const skey = seg_key[wave];
+        unsigned* const sidx = seg_idx[wave];
+        int seg_len = 0;
+        if (seg_sorted) {
+            // (at most SEG_SORT_MAX candidates: the sort kernel checked; all chunks' loads are issued together: three
+            //  round trips to memory for the segment instead of three per chunk)
+            constexpr int CH = SEG_SORT_MAX / 64;
+            unsigned kq[CH], oq[CH];
+            float sq[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const unsigned t = start + 64 * q + lane;
+                kq[q] = t < img_end ? p.keyA[t] : ~key;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const unsigned t = start + 64 * q + lane;
+                oq[q] = kq[q] == key ? p.valA[t] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) sq[q] = kq[q] == key ? p.scores[oq[q]] : 0.f;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const bool valid = kq[q] == key;   // the segment is contiguous: valid lanes form a prefix
+                if (valid) {
+                    unsigned u = __float_as_uint(sq[q]);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    skey[64 * q + lane] = ~u;
+                    sidx[64 * q + lane] = oq[q];
+                }
+                seg_len += __popcll(__ballot(valid));
+            }
+            const int len4 = (seg_len + 3) & ~3;
+            if (seg_len + lane < len4) skey[seg_len + lane] = 0xFFFFFFFFu;   // padding never precedes anything
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            constexpr int OWN = SEG_SORT_MAX / 64;
+            unsigned mykey[OWN], myidx[OWN], rank[OWN];
+#pragma unroll
+            for (int q = 0; q < OWN; ++q) {
+                const int e = lane + 64 * q;
+                mykey[q] = e < seg_len ? skey[e] : 0u;
+                myidx[q] = e < seg_len ? sidx[e] : 0u;
+                rank[q] = 0;
+            }
+            const int nown = (seg_len + 63) / 64;   // wave-uniform: groups of 64 candidates in use
+            switch (nown) {
+                case 1: rank_by_counting<1>(skey, len4, mykey, rank); break;
+                case 2: rank_by_counting<2>(skey, len4, mykey, rank); break;
+                case 3: rank_by_counting<3>(skey, len4, mykey, rank); break;
+                case 4: rank_by_counting<4>(skey, len4, mykey, rank); break;
+                case 5: rank_by_counting<5>(skey, len4, mykey, rank); break;
+                case 6: rank_by_counting<6>(skey, len4, mykey, rank); break;
+                case 7: rank_by_counting<7>(skey, len4, mykey, rank); break;
+                default: rank_by_counting<8>(skey, len4, mykey, rank); break;
+            }
+            // the candidates in rank order (every lane read its own candidate indices above)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int q = 0; q < OWN; ++q)
+                if (lane + 64 * q < seg_len) sidx[rank[q]] = myidx[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // Two candidates that the fast count cannot tell apart (equal keys inside one group of 64) got the SAME
+            // rank: one of them does not find itself in its slot.  Then (rare) the ranks are counted again with the
+            // position test on every pair.
+            bool lost = false;
+#pragma unroll
+            for (int q = 0; q < OWN; ++q)
+                if (lane + 64 * q < seg_len && sidx[rank[q]] != myidx[q]) lost = true;
+            if (__ballot(lost)) {
+#pragma unroll
+                for (int q = 0; q < OWN; ++q) rank[q] = 0;
+                for (int j = 0; j < seg_len; ++j) {
+                    const unsigned k = skey[j];
+#pragma unroll
+                    for (int q = 0; q < OWN; ++q)
+                        rank[q] += (k < mykey[q] || (k == mykey[q] && j < lane + 64 * q)) ? 1u : 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                for (int q = 0; q < OWN; ++q)
+                    if (lane + 64 * q < seg_len) sidx[rank[q]] = myidx[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
         for (unsigned cs = start; cs < img_end && nkept < kcap; cs += 64) {
             const unsigned t = cs + lane;
             bool valid = t < img_end;
-            if (valid) valid = p.keyA[t] == key;
+            if (seg_sorted)
+                valid = (int)(cs - start) + lane < seg_len;
+            else if (valid)
+                valid = p.keyA[t] == key;
             const unsigned long long vmask = __ballot(valid);
             if (vmask == 0) break;
             unsigned posB = 0;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (valid) {
-                posB = p.valA[t];
-                const unsigned orig = p.valB[posB];
+                unsigned orig;
+                if (seg_sorted) {
+                    orig = sidx[cs - start + lane];
+                    posB = orig;   // what is recorded for a kept box: the candidate itself
+                } else {
+                    posB = p.valA[t];
+                    orig = p.valB[posB];
+                }
                 b = *(const f32x4*)(p.boxes + 4ull * orig);
                 if (agn) shift = (float)p.classes[orig] * unit;
                 if (trick) {
@@ -573,7 +783,10 @@ __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
             const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
             const int r = nkept + __popcll(amask & lt);
             if (alive && r < kcap) {
-                p.keepB[posB] = 1;
+                if (seg_sorted)
+                    p.valB[start + r] = posB;   // the segment's kept candidates in score order (valB is free: no order B)
+                else
+                    p.keepB[posB] = 1;
                 if (r < KEPT_LDS) klds[r] = b; else kspill[r - KEPT_LDS] = b;
             }
             nkept += __popcll(amask);
@@ -582,6 +795,24 @@ __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (!(vmask >> 63)) break;  // the segment ended inside this chunk
+        }
+        if (seg_sorted && lane == 0) p.sort_k0[start] = (unsigned)(nkept < kcap ? nkept : kcap);   // length of that list
+    }
+}
+
+// rk[q] += the number of offers in offer[0 .. T4) (T4 a multiple of 4) that are smaller than mine[q], q < NQ.
+template <int NQ>
+__device__ __forceinline__ void count_smaller_offers(const unsigned long long* offer, int T4,
+                                                     const unsigned long long (&mine)[MERGE_MAX / 256],
+                                                     unsigned (&rk)[MERGE_MAX / 256]) {
+    for (int j = 0; j < T4; j += 4) {
+        unsigned long long k[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k[i] = offer[j + i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rk[q] += k[i] < mine[q] ? 1u : 0u;
         }
     }
 }
@@ -594,6 +825,119 @@ __global__ void __launch_bounds__(256) nms_emit_kernel(const NmsParams p) {
     const int b = img_begin(p, n), e = img_begin(p, n + 1);
     const int limit = p.top_k > 0 ? (p.top_k < p.keep_stride ? p.top_k : p.keep_stride) : p.keep_stride;
     int* out = p.keep + (long long)n * p.keep_stride;
+    if (e - b > 0 && p.agnostic[n] == IMG_SEGMENT_SORTED) {
+        // ---- merge of the segments' kept lists (each in score order, at most top_k long) into the image's first
+        //      `limit` detections, in rounds: every segment OFFERS its next R kept candidates (R = as many as fit MERGE_MAX
+        //      offers over all segments); the offers are ranked by counting ((key, candidate index): torch's order); they
+        //      are accepted in that order up to and including the first one that is the LAST offer of a segment which still
+        //      has more -- what follows in that segment may precede the remaining offers, so the next round starts there.
+        //      An offer is ONE 64-bit value, key in the high word and candidate index in the low word: real offers are all
+        //      different, an empty slot is all ones and precedes nothing.
+        __shared__ __attribute__((aligned(16))) unsigned long long offer[MERGE_MAX + 4];
+        __shared__ unsigned seg_ptr[256], seg_len[256], seg_at[256];
+        __shared__ int cut_s, emitted_s;
+        const unsigned seg_base = p.sort_v0[b];
+        const int nsegs = (int)p.sort_v0[b + 1];   // <= 2^cbits <= 256
+        if (tid < nsegs) {
+            const unsigned at = p.seg_start[seg_base + tid];
+            seg_at[tid] = at;
+            seg_len[tid] = p.sort_k0[at];
+            seg_ptr[tid] = 0;
+        }
+        if (tid == 0) emitted_s = 0;
+        __syncthreads();
+        // offers per segment and round: about four times a segment's fair share of the output (a round costs a ranking
+        // that is quadratic in the offers; a segment that contributes more than its offers costs another round)
+        int R = NMS_MERGE_SHARE * limit / (nsegs > 0 ? nsegs : 1) + 2;
+        R = R < MERGE_MAX / (nsegs > 0 ? nsegs : 1) ? R : MERGE_MAX / (nsegs > 0 ? nsegs : 1);
+        R = R < limit ? R : (limit > 0 ? limit : 1);
+        const int T = R * nsegs;   // offer slots of a round: slot o = segment o / R, its (o % R)-th next candidate
+        while (true) {
+            const int emitted = emitted_s;
+            if (emitted >= limit) break;
+            // offers (two dependent loads each, all of a thread's slots requested together)
+            constexpr int PER = MERGE_MAX / 256;
+            unsigned oi[PER];
+            unsigned long long mine[PER];
+            bool have[PER], last_more[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int o = tid + 256 * q;
+                have[q] = false;
+                last_more[q] = false;
+                oi[q] = 0;
+                if (o < T) {
+                    const int sg = o / R, r = o - sg * R;
+                    const unsigned pos = seg_ptr[sg] + (unsigned)r;
+                    if (pos < seg_len[sg]) {
+                        have[q] = true;
+                        last_more[q] = r == R - 1 && pos + 1 < seg_len[sg];
+                        oi[q] = p.valB[seg_at[sg] + pos];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                mine[q] = ~0ull;
+                if (have[q]) {
+                    unsigned u = __float_as_uint(p.scores[oi[q]]);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    mine[q] = ((unsigned long long)(~u) << 32) | oi[q];
+                }
+            }
+            if (tid == 0) cut_s = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int o = tid + 256 * q;
+                if (o < T) offer[o] = mine[q];
+            }
+            if (tid < 4) offer[T + tid] = ~0ull;   // padding up to a multiple of four
+            __syncthreads();
+            // rank of every real offer among the offers
+            const int T4 = (T + 3) & ~3;
+            const int nq = (T + 255) >> 8;   // slots in use per thread
+            unsigned rk[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) rk[q] = 0;
+            switch (nq) {
+                case 1: count_smaller_offers<1>(offer, T4, mine, rk); break;
+                case 2: count_smaller_offers<2>(offer, T4, mine, rk); break;
+                case 3: count_smaller_offers<3>(offer, T4, mine, rk); break;
+                default: count_smaller_offers<4>(offer, T4, mine, rk); break;
+            }
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+                if (have[q] && last_more[q]) atomicMin(&cut_s, (int)rk[q]);
+            __syncthreads();
+            int total = 0;   // real offers of this round
+            {
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) cnt += have[q] ? 1 : 0;
+                // workgroup sum through the wave sums
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+                if (lane == 0) wsum[wave] = cnt;
+                __syncthreads();
+                total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            }
+            if (total == 0) break;   // every list is used up
+            int accept = cut_s == 0x7fffffff ? total : cut_s + 1;
+            if (accept > limit - emitted) accept = limit - emitted;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                if (have[q] && (int)rk[q] < accept) {
+                    out[emitted + (int)rk[q]] = (int)oi[q] - b;
+                    atomicAdd(&seg_ptr[(tid + 256 * q) / R], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) emitted_s = emitted + accept;
+            __syncthreads();
+        }
+        if (tid == 0) p.n_keep[n] = emitted_s < limit ? emitted_s : limit;
+        return;
+    }
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = b; base < e; base += 256) {
