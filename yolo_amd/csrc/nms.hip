@@ -255,6 +255,9 @@ __device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* k
 
 constexpr int SORT_SMALL = 1024;     // table size of the counting path (one entry per thread)
 constexpr int MERGE_MAX = 1024;     // offers per merge round in the emit kernel
+#ifndef NMS_SEGMENT_SORT_MIN
+#define NMS_SEGMENT_SORT_MIN 0        // candidates per image from which the class-only sort is used (tunable)
+#endif
 #ifndef NMS_MERGE_SHARE
 #define NMS_MERGE_SHARE 4            // offers per segment and round, in units of a segment's fair share of top_k (tunable)
 #endif
@@ -385,7 +388,7 @@ __global__ void __launch_bounds__(SORT_THREADS) nms_sort_kernel(const NmsParams 
     //      then candidate index); each segment is put into score order by the wave that sweeps it, and the emit kernel
     //      merges the segments' kept lists.  The four passes over the scores -- what a single workgroup per image spends
     //      most of its time on when an image has tens of thousands of candidates -- are not needed for the first top_k.
-    if (p.top_k > 0 && p.cbits <= RADIX_BITS && agnostic_s == 0) {
+    if (p.top_k > 0 && p.cbits <= RADIX_BITS && agnostic_s == 0 && m >= NMS_SEGMENT_SORT_MIN) {
         for (int i0 = 0; i0 < m; i0 += SORT_TILE) {
             unsigned cl[SORT_E];
 #pragma unroll
