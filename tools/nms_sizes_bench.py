@@ -1,5 +1,5 @@
 """Time of the batched NMS with top-100 over candidates per image (uniform stress boxes, 80 classes), batches of 1 and 32:
-where the class-only sort with per-segment ordering and list merge pays against the two-order sort.
+where grouping by class with per-segment ordering and a list merge pays against the two-order sort.
 usage: [YOLO_HIP_LIB=variant.so] python tools/nms_sizes_bench.py [reps]"""
 import json
 import os

@@ -17,6 +17,10 @@
 //      wave ballots + lane broadcasts.  IoU arithmetic is fp32 in torchvision's operation order; the file is built
 //      with -ffp-contract=off.
 //   3. emit kernel, one workgroup per image: walks order B, ranks the kept flags and emits the first top_k.
+//   With top_k > 0 and no class of the image above 512 candidates, 1-3 take a shorter form: the sort kernel only groups
+//   the candidates by class (counting sort through LDS atomics), the sweeping wave puts its segment into (score,
+//   candidate index) order itself before the sweep and leaves its kept candidates as a list, and the emit kernel merges
+//   the image's lists up to top_k.  Same kept indices in the same order.
 //
 // The coordinate-trick branch of torchvision (boxes shifted by class * (max_coordinate + 1) before a single
 // class-agnostic NMS) is reproduced by applying the same fp32 shift to the boxes of each (image, class) segment.
@@ -256,7 +260,7 @@ __device__ bool radix_pass(const unsigned* kin, const unsigned* vin, unsigned* k
 constexpr int SORT_SMALL = 1024;     // table size of the counting path (one entry per thread)
 constexpr int MERGE_MAX = 1024;     // offers per merge round in the emit kernel
 #ifndef NMS_SEGMENT_SORT_MIN
-#define NMS_SEGMENT_SORT_MIN 0        // candidates per image from which the class-only sort is used (tunable)
+#define NMS_SEGMENT_SORT_MIN 0        // candidates per image from which the grouping-by-class form is used (tunable)
 #endif
 #ifndef NMS_MERGE_SHARE
 #define NMS_MERGE_SHARE 4            // offers per segment and round, in units of a segment's fair share of top_k (tunable)
@@ -384,61 +388,71 @@ __global__ void __launch_bounds__(SORT_THREADS) nms_sort_kernel(const NmsParams 
     }
     unsigned* kbuf[2] = {p.sort_k0 + b, p.sort_k1 + b};
     unsigned* vbuf[2] = {p.sort_v0 + b, p.sort_v1 + b};
-    // ---- top-k, per-class segments of moderate size: only the CLASS pass runs here (one stable pass: order A' = class,
-    //      then candidate index); each segment is put into score order by the wave that sweeps it, and the emit kernel
-    //      merges the segments' kept lists.  The four passes over the scores -- what a single workgroup per image spends
-    //      most of its time on when an image has tens of thousands of candidates -- are not needed for the first top_k.
+    // ---- top-k, per-class segments of moderate size: the candidates are only GROUPED by class here (a counting sort
+    //      through LDS atomics: order inside a class is whatever the atomics give); each segment is put into (score,
+    //      candidate index) order by the wave that sweeps it, and the emit kernel merges the segments' kept lists.  The
+    //      four passes over the scores -- what a single workgroup per image spends most of its time on when an image
+    //      has tens of thousands of candidates -- are not needed for the first top_k.
     if (p.top_k > 0 && p.cbits <= RADIX_BITS && agnostic_s == 0 && m >= NMS_SEGMENT_SORT_MIN) {
-        for (int i0 = 0; i0 < m; i0 += SORT_TILE) {
-            unsigned cl[SORT_E];
-#pragma unroll
-            for (int e = 0; e < SORT_E; ++e) {
-                const int i = i0 + e * SORT_THREADS + tid;
-                cl[e] = (unsigned)p.classes[b + (i < m ? i : m - 1)];
-            }
-#pragma unroll
-            for (int e = 0; e < SORT_E; ++e) {
-                const int i = i0 + e * SORT_THREADS + tid;
-                if (i < m) kbuf[0][i] = cl[e];
-            }
-        }
-        __syncthreads();
-        radix_histograms(kbuf[0], m, 1, sh);   // the digit IS the class: hist[0][c] = size of segment c
+        __shared__ unsigned cls_cnt[RADIX_BINS], scan_cnt[SORT_WAVES], scan_seg[SORT_WAVES];
         __shared__ int seg_too_long;
+        if (tid < RADIX_BINS) cls_cnt[tid] = 0;
         if (tid == 0) seg_too_long = 0;
         __syncthreads();
-        if (tid < RADIX_BINS && sh.hist[0][tid] > (unsigned)SEG_SORT_MAX) seg_too_long = 1;
+        for (int i = tid; i < m; i += SORT_THREADS) atomicAdd(&cls_cnt[(unsigned)p.classes[b + i] & (RADIX_BINS - 1)], 1u);
+        __syncthreads();
+        if (tid < RADIX_BINS && cls_cnt[tid] > (unsigned)SEG_SORT_MAX) seg_too_long = 1;
         __syncthreads();
         if (seg_too_long == 0) {
-            const bool moved = radix_pass(kbuf[0], nullptr, kbuf[1], vbuf[1], m, 0, sh);
-            const unsigned* ck = moved ? kbuf[1] : kbuf[0];
-            const unsigned* cv = moved ? vbuf[1] : nullptr;   // candidate index inside the image (identity if nothing moved)
-            const unsigned nkey = (unsigned)n << p.cbits;
-            unsigned heads = 0;
-            for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
+            // exclusive scans over the classes: candidates (where a class starts) and non-empty classes (its segment)
+            unsigned cnt = 0, incl = 0, has = 0, sincl = 0;
+            if (tid < RADIX_BINS) {
+                cnt = cls_cnt[tid];
+                has = cnt ? 1u : 0u;
+                incl = cnt;
+                sincl = has;
 #pragma unroll
-                for (int e = 0; e < SORT_E; ++e) {
-                    const int t = t0 + e * SORT_THREADS + tid;
-                    if (t < m) {
-                        const unsigned c = ck[t], cp = t > 0 ? ck[t - 1] : ~0u;
-                        p.keyA[b + t] = nkey | c;
-                        p.valA[b + t] = (unsigned)b + (cv ? cv[t] : (unsigned)t);   // the candidate itself (there is no order B)
-                        heads += cp != c ? 1u : 0u;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned t = __shfl_up(incl, d, 64), u = __shfl_up(sincl, d, 64);
+                    if (lane >= d) {
+                        incl += t;
+                        sincl += u;
                     }
                 }
-            }
-            if (heads) atomicAdd(&seg_count, heads);
-            __syncthreads();
-            if (tid == 0) seg_base = atomicAdd(p.nseg, seg_count);
-            __syncthreads();
-            for (int t0 = 0; t0 < m; t0 += SORT_TILE) {
-#pragma unroll
-                for (int e = 0; e < SORT_E; ++e) {
-                    const int t = t0 + e * SORT_THREADS + tid;
-                    if (t < m && (t == 0 || ck[t - 1] != ck[t])) p.seg_start[seg_base + atomicAdd(&seg_next, 1u)] = (unsigned)(b + t);
+                if (lane == 63) {
+                    scan_cnt[wave] = incl;
+                    scan_seg[wave] = sincl;
                 }
             }
-            __syncthreads();   // ck (possibly sort_k0) has been read for the last time
+            __syncthreads();
+            unsigned base = 0, sbase = 0;
+            if (tid < RADIX_BINS) {
+                for (int w = 0; w < wave; ++w) {
+                    base += scan_cnt[w];
+                    sbase += scan_seg[w];
+                }
+                base += incl - cnt;
+                sbase += sincl - has;
+            }
+            if (tid == 0) {
+                unsigned nsegs = 0;
+                for (int w = 0; w < RADIX_BINS / 64; ++w) nsegs += scan_seg[w];
+                seg_count = nsegs;
+                seg_base = atomicAdd(p.nseg, nsegs);
+            }
+            __syncthreads();   // (every count has been read: the table now holds each class's next free position)
+            if (tid < RADIX_BINS) {
+                cls_cnt[tid] = base;
+                if (has) p.seg_start[seg_base + sbase] = (unsigned)b + base;
+            }
+            __syncthreads();
+            const unsigned nkey = (unsigned)n << p.cbits;
+            for (int i = tid; i < m; i += SORT_THREADS) {
+                const unsigned c = (unsigned)p.classes[b + i];
+                const unsigned pos = atomicAdd(&cls_cnt[c & (RADIX_BINS - 1)], 1u);
+                p.keyA[b + pos] = nkey | c;
+                p.valA[b + pos] = (unsigned)(b + i);   // the candidate itself (there is no order B)
+            }
             if (tid == 0) {
                 p.agnostic[n] = IMG_SEGMENT_SORTED;
                 p.sort_v0[b] = seg_base;       // this image's entries of seg_start: the emit kernel merges them
@@ -580,30 +594,18 @@ __device__ __forceinline__ f32x4 bcast_box(const f32x4 b, int srclane) {
 
 // Ranks of a segment's candidates by counting, for the wave that owns the segment.  skey[0 .. len4) holds the keys
 // (ascending key = descending score; padded to a multiple of 4 with 0xFFFFFFFF), lane l owns the candidates at
-// positions l + 64 q, q < NOWN, whose keys are mykey[q].  The order wanted is (key, position):
-//   rank_e = #{j : key_j < key_e} + #{j < e : key_j == key_e}.
-// Positions of another group of 64 than e's are all before or all behind e, so against those the test is ONE unsigned
-// compare, with key_e + 1 (groups before) or key_e (groups behind) as the bound.  e's own group is counted with key_e
-// as well, which leaves out equal keys at lower positions of the same group -- and with key 0xFFFFFFFF (no +1) equal
-// keys of earlier groups: in both cases the candidates concerned end with EQUAL ranks, which the caller detects.
+// positions l + 64 q, q < NOWN, whose keys are mykey[q].  rank_e = #{j : key_j < key_e}: ONE unsigned compare per pair.
+// Candidates with equal keys end with EQUAL ranks, which the caller detects and resolves by candidate index.
 template <int NOWN>
 __device__ __forceinline__ void rank_by_counting(const unsigned* skey, int len4, const unsigned (&mykey)[SEG_SORT_MAX / 64],
                                                  unsigned (&rank)[SEG_SORT_MAX / 64]) {
-    unsigned keyp1[NOWN];
-#pragma unroll
-    for (int q = 0; q < NOWN; ++q) keyp1[q] = mykey[q] == 0xFFFFFFFFu ? mykey[q] : mykey[q] + 1u;
-#pragma unroll
-    for (int c = 0; c < NOWN; ++c) {
-        const int jend = c == NOWN - 1 ? len4 - 64 * c : 64;
 #pragma unroll 2
-        for (int jj = 0; jj < jend; jj += 4) {
-            const u32x4 k = *(const u32x4*)(skey + 64 * c + jj);
+    for (int j = 0; j < len4; j += 4) {
+        const u32x4 k = *(const u32x4*)(skey + j);
 #pragma unroll
-            for (int q = 0; q < NOWN; ++q) {
-                const unsigned thr = c < q ? keyp1[q] : mykey[q];
+        for (int q = 0; q < NOWN; ++q) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rank[q] += k[i] < thr ? 1u : 0u;
-            }
+            for (int i = 0; i < 4; ++i) rank[q] += k[i] < mykey[q] ? 1u : 0u;
         }
     }
 }
@@ -627,17 +629,17 @@ __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
         const int m_img = (int)img_end - img_begin(p, n);
         const bool trick = p.mode == YOLO_NMS_COORD_TRICK || (p.mode == YOLO_NMS_AUTO && 4ll * m_img <= p.auto_limit);
         const bool agn = p.agnostic[n] == IMG_AGNOSTIC;  // the whole image is this one segment; every box shifts by its own class
-        const bool seg_sorted = p.agnostic[n] == IMG_SEGMENT_SORTED;  // order A' (class, index): this wave sorts the segment by score
+        const bool seg_sorted = p.agnostic[n] == IMG_SEGMENT_SORTED;  // grouped by class only: this wave sorts the segment by score
         // torchvision: offsets = idxs.to(boxes) * (max_coordinate + 1); boxes_for_nms = boxes + offsets
         const float unit = p.img_max[n] + 1.0f;
         float shift = trick ? (float)cls * unit : 0.0f;
         f32x4* kspill = p.kept_spill + start;
         int nkept = 0;
         const int kcap = p.top_k > 0 ? p.top_k : 0x7fffffff;
-        // ---- a segment in (class, index) order: this wave puts it into score order first.  Keys (descending score =
-        //      ascending key) and candidate indices go to LDS; every lane ranks its candidates by COUNTING the ones
-        //      that precede them (key, then position = candidate index: torch's stable order), reading the keys four
-        //      per LDS instruction as broadcasts; the candidates are then written back in rank order.
+        // ---- a segment that is only grouped by class: this wave puts it into score order first.  Keys (descending score
+        //      = ascending key) and candidate indices go to LDS; every lane ranks its candidates by COUNTING the ones
+        //      that precede them, reading the keys four per LDS instruction as broadcasts; the candidates are then
+        //      written back in rank order (equal scores: by candidate index, torch's stable order).
         unsigned* const skey = seg_key[wave];
         unsigned* const sidx = seg_idx[wave];
         int seg_len = 0;
@@ -705,21 +707,52 @@ __global__ void __launch_bounds__(256) nms_sweep_kernel(const NmsParams p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // Two candidates that the fast count cannot tell apart (equal keys inside one group of 64) got the SAME
-            // rank: one of them does not find itself in its slot.  Then (rare) the ranks are counted again with the
-            // position test on every pair.
-            bool lost = false;
+            // Candidates with equal keys got the SAME rank: all but one of them do not find themselves in their slot.
+            // Then (rare), key by key: the candidates that hold the key are enumerated through ballots, and each of them
+            // moves up by the number of holders with a lower candidate index -- torch's order among equal scores.
+            bool lostq[OWN];
+            unsigned long long any_lost = 0;
 #pragma unroll
-            for (int q = 0; q < OWN; ++q)
-                if (lane + 64 * q < seg_len && sidx[rank[q]] != myidx[q]) lost = true;
-            if (__ballot(lost)) {
+            for (int q = 0; q < OWN; ++q) {
+                lostq[q] = lane + 64 * q < seg_len && sidx[rank[q]] != myidx[q];
+                any_lost |= __ballot(lostq[q]);
+            }
+            if (any_lost) {
+                while (true) {
+                    int fq = -1;
+                    unsigned long long fm = 0;
 #pragma unroll
-                for (int q = 0; q < OWN; ++q) rank[q] = 0;
-                for (int j = 0; j < seg_len; ++j) {
-                    const unsigned k = skey[j];
+                    for (int q = 0; q < OWN; ++q) {
+                        const unsigned long long bm = __ballot(lostq[q]);
+                        if (fq < 0 && bm) {
+                            fq = q;
+                            fm = bm;
+                        }
+                    }
+                    if (fq < 0) break;   // every pass clears at least the candidate it started from
+                    const int fl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(fm));
+                    unsigned K = 0;
 #pragma unroll
                     for (int q = 0; q < OWN; ++q)
-                        rank[q] += (k < mykey[q] || (k == mykey[q] && j < lane + 64 * q)) ? 1u : 0u;
+                        if (q == fq) K = __builtin_amdgcn_readlane(mykey[q], fl);
+                    bool holds[OWN];
+#pragma unroll
+                    for (int q = 0; q < OWN; ++q) holds[q] = lane + 64 * q < seg_len && mykey[q] == K;
+#pragma unroll
+                    for (int qa = 0; qa < OWN; ++qa) {
+                        unsigned long long tm = __ballot(holds[qa]);
+                        while (tm) {
+                            const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tm));
+                            tm &= tm - 1;
+                            const unsigned other = __builtin_amdgcn_readlane(myidx[qa], l);
+#pragma unroll
+                            for (int qb = 0; qb < OWN; ++qb)
+                                if (holds[qb] && other < myidx[qb]) ++rank[qb];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < OWN; ++q)
+                        if (holds[q]) lostq[q] = false;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
