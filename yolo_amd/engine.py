@@ -68,6 +68,18 @@ class InFlight:
     geom: Tuple[int, int, int]  # N, stored image height, width
 
 
+@dataclass
+class _GraphedDetect:
+    """One captured detect() call: the HIP graph, its static input, its static outputs, the batch record of the
+    captured call (plan and candidate buffers: kept alive with the graph) and the size tensors the gather reads."""
+    graph: "torch.cuda.CUDAGraph"
+    static_in: torch.Tensor
+    det: torch.Tensor
+    n_det: torch.Tensor
+    in_flight: InFlight
+    sizes: tuple
+
+
 class Yolov3Engine:
     """Packs a DarkNetFPN module's parameters once and runs batches through cached plans."""
 
@@ -99,6 +111,9 @@ class Yolov3Engine:
         # measurement hook: when a list, submit()/finish() append (label, start event, end event) recorded on the
         # stream the decode / NMS + gather launches run on
         self.trace_events: Optional[list] = None
+        # detect_graphed(): call signature -> captured HIP graph of one detect() with its static input and outputs
+        self._graphs: Dict[tuple, "_GraphedDetect"] = {}
+        self._graph_seen: Dict[tuple, int] = {}
         self.repack()
 
     # ------------------------------------------------------------------ weights
@@ -114,6 +129,7 @@ class Yolov3Engine:
                 pw, pb = ops.pack_conv(w, b, self.dtype, self.device)
             self._packed[name] = PackedConv(pw, pb, conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride)
         self._plans.clear()
+        self._graphs.clear()   # captured launches point at the old packed weights
 
     # ------------------------------------------------------------------ plan
     @ops.on_own_device
@@ -355,8 +371,9 @@ class Yolov3Engine:
             self._trace_end("nms_gather", t0)
         if side is not main:
             main.wait_stream(side)
-            det.record_stream(main)
-            n_det.record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():   # (a captured graph owns its outputs)
+                det.record_stream(main)
+                n_det.record_stream(main)
         return det, n_det
 
     def grow_candidates(self, h: "InFlight", total: Optional[int] = None) -> bool:
@@ -366,6 +383,9 @@ class Yolov3Engine:
         over = self.overflowed(h) if total is None else max(0, int(total) - h.cand.scores.numel())
         if over:
             h.plan.cand_cap = int((h.cand.scores.numel() + over) * 1.25) + 1024
+            # captured graphs of this plan hold the old candidate buffers
+            for key in [k for k, g in self._graphs.items() if g.in_flight.plan is h.plan]:
+                del self._graphs[key]
         return over > 0
 
     def overflowed(self, h: "InFlight") -> int:
@@ -417,6 +437,51 @@ class Yolov3Engine:
                           in_hw=in_hw, out_hw=out_hw)
         self.last_in_flight = h
         return out
+
+    GRAPH_AFTER = 3    # detect_graphed() captures a call signature when it comes for the third time
+    GRAPH_KEEP = 8     # captured signatures kept (least recently used first out)
+
+    @ops.on_own_device
+    def detect_graphed(self, images: torch.Tensor, *, score_thr: float, nms_thr: float, mean, std,
+                       padded_hw=None, max_det: int = 100, nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000,
+                       in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
+        """detect() for latency-bound callers (one or a few images per call, the same shapes again and again): the
+        ~130 launches of a call -- convolutions, split-k sums, decode, NMS, gather, with their stream forks and joins --
+        are captured ONCE per call signature into a HIP graph and replayed with a single launch, so the host's share of
+        a call no longer grows with the number of layers.  A signature is captured when it has been seen
+        ``GRAPH_AFTER`` times (calls before that, and signatures that keep changing, run detect() as it is); the input
+        is copied into the graph's static input buffer, the returned tensors are the graph's static outputs: valid
+        until the next call with the same signature, like the buffers of a plan.  ``last_in_flight`` is set as by
+        detect()."""
+        kw = dict(score_thr=score_thr, nms_thr=nms_thr, mean=mean, std=std, padded_hw=padded_hw, max_det=max_det,
+                  nms_mode=nms_mode, auto_limit=auto_limit, in_hw=in_hw, out_hw=out_hw)
+        key = (tuple(images.shape), images.dtype, float(score_thr), float(nms_thr), tuple(float(m) for m in mean),
+               tuple(float(v) for v in std), padded_hw, int(max_det), int(nms_mode), int(auto_limit),
+               None if in_hw is None else in_hw.data_ptr(), None if out_hw is None else out_hw.data_ptr())
+        g = self._graphs.pop(key, None)
+        if g is None:
+            seen = self._graph_seen.get(key, 0) + 1
+            if len(self._graph_seen) > 256:
+                self._graph_seen.clear()
+            self._graph_seen[key] = seen
+            if seen < self.GRAPH_AFTER:
+                return self.detect(images, **kw)
+            static_in = images.clone()
+            # plan, candidate buffers, workspaces, side streams and kernel attributes exist after an eager call; the
+            # capture itself must allocate nothing but its outputs
+            self.detect(static_in, **kw)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                det, n_det = self.detect(static_in, **kw)
+            g = _GraphedDetect(graph, static_in, det, n_det, self.last_in_flight, (in_hw, out_hw))
+            while len(self._graphs) >= self.GRAPH_KEEP:
+                self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = g   # most recently used last
+        g.static_in.copy_(images, non_blocking=True)
+        g.graph.replay()
+        self.last_in_flight = g.in_flight
+        return g.det, g.n_det
 
     def detect_pipelined(self, batches, *, score_thr: float, nms_thr: float, mean, std, max_det: int = 100,
                          nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000, depth: int = 2):

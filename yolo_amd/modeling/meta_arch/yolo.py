@@ -8,6 +8,8 @@ image.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List
 
 import torch
@@ -117,6 +119,12 @@ class YOLOV3(nn.Module):
         hip = cfg.MODEL.get("HIP", None)
         self.nms_mode = _NMS_MODES[hip.NMS_MODE] if hip is not None else ops.NMS_AUTO
         self.nms_auto_numel = hip.NMS_AUTO_NUMEL if hip is not None else 20000
+        # inference calls with at most this many images replay a captured HIP graph (Yolov3Engine.detect_graphed);
+        # 0 = never (the default: a single-image call is bound by its kernels, not by the host's launches, and the
+        # replay measured within 0-4 % of launching one by one).  YOLO_HIP_GRAPH=1 switches it on for up to
+        # YOLO_HIP_GRAPH_MAX_BATCH (8) images.
+        self.graph_max_batch = int(os.environ.get("YOLO_HIP_GRAPH_MAX_BATCH", "8")) \
+            if os.environ.get("YOLO_HIP_GRAPH", "0") == "1" else 0
 
     @property
     def device(self):
@@ -347,8 +355,11 @@ class YOLOV3(nn.Module):
         in_hw, out_hw = self._size_tensors(tuple(sizes), tuple(out))
         eng = self.backbone.engine()
         N = len(sizes)
+        # few images per call: the call's launches are replayed from a captured HIP graph once the same call signature
+        # has come a few times (off unless YOLO_HIP_GRAPH=1 / model.graph_max_batch is set)
+        detect = eng.detect_graphed if (self.graph_max_batch and N <= self.graph_max_batch) else eng.detect
         for _ in range(2):
-            det, n_det = eng.detect(
+            det, n_det = detect(
                 batch, score_thr=self.test_score_thresh, nms_thr=self.test_nms_thresh, mean=self._mean, std=self._std,
                 max_det=self.max_detections_pre_image, nms_mode=self.nms_mode, auto_limit=self.nms_auto_numel,
                 in_hw=in_hw, out_hw=out_hw)
