@@ -142,7 +142,10 @@ class Yolov3Inference:
                         "preprocess + backbone + neck + heads + decode + batched NMS + top-100",
             "batch_per_gpu": BATCH, "global_batch": BATCH * world, "input": [SIZE, SIZE],
             "score_thresh": self.thr, "nms_thresh": self.nms_thr, "parallelism": f"image-sharded x{world}, no collective",
-            "weights": "random init (reference initialisers), BatchNorm statistics calibrated on the synthetic images",
+            "weights": "random init (reference initialisers), BatchNorm statistics calibrated on the synthetic images; "
+                       "the three head convolutions rescaled so that their logits have unit standard deviation on those "
+                       "images and the objectness bias set to -4.5 (that fixes the post-processing load: see "
+                       "candidates_per_batch / detections_per_batch)",
             "candidates_per_batch": int(plan.cand.img_offsets[BATCH].item()),
             "detections_per_batch": int(n_det.sum().item()),
             "conv_gflop_per_image": round(plan.flops / BATCH / 1e9, 3),
@@ -161,12 +164,16 @@ class Yolov3Inference:
         return _cpu_baseline(self.model, self.cfg)
 
     def train(self) -> dict:
-        del self.last
+        """Collective when world > 1: every rank calls it (data-parallel training step, gradients exchanged over
+        the process group); rank 0's record is the one printed."""
+        self.last = None
         self.eng._plans.clear()
         self.torch.cuda.empty_cache()
         try:
-            return _train_throughput()
+            return _train_throughput(rank=self.rank, world=self.world)
         except Exception as e:  # the headline line must not depend on the secondary measurement
+            if self.world > 1:
+                raise  # a rank that left the collective would leave its peers waiting: fail the job instead
             return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
@@ -363,30 +370,53 @@ def _cpu_baseline(model, cfg):
                 images_per_sec=rows)
 
 
-def _train_throughput(steps: int = 4, warmup: int = 2, batch: int = 64):
-    """Secondary metric of the same hot path (training images per second): forward + backward + SGD step of
-    configs/yolov3.yaml at 416x416, batch 64, bf16, synthetic COCO-shaped targets, on this one GPU."""
+def _train_throughput(steps: int = 4, warmup: int = 2, batch: int = 64, rank: int = 0, world: int = 1):
+    """Secondary metric of the same hot path (training images per second): forward + backward + gradient exchange +
+    SGD step of configs/yolov3.yaml at 416x416, bf16, synthetic COCO-shaped targets, ``batch`` images per GPU.  With
+    world > 1 this is the data-parallel step of the reference's ``launch(main, num_gpus)`` -> DefaultTrainer -> DDP
+    (tools/train_net.py:117-147): every rank runs its own images, gradients are exchanged bucket by bucket from
+    inside the backward pass (yolo_amd.utils.dist.GradBucketer) over the process group bench.py initialised (RCCL);
+    the region is bracketed by a barrier + synchronize and the MAX over ranks is taken, like the headline."""
     import torch
 
     import workload
     from yolo_amd.trainer import Trainer, synthetic_batches
+    from yolo_amd.utils import dist as D
     model, cfg = workload.build_model(config="yolov3.yaml", dtype="bf16", device=f"cuda:{torch.cuda.current_device()}",
                                       opts=["OUTPUT_DIR", "", "SOLVER.CHECKPOINT_PERIOD", 0, "SOLVER.BASE_LR", 1e-4])
-    data = next(synthetic_batches(cfg, batch, SIZE, seed=7, device=model.device))
-    tr = Trainer(cfg, model, iter(lambda: data, None), log=lambda m: None)
+    data = next(synthetic_batches(cfg, batch, SIZE, seed=7 + rank, device=model.device))
+    tr = Trainer(cfg, model, iter(lambda: data, None), log=lambda m: None)   # world > 1: broadcasts rank 0's weights
     for _ in range(warmup):
         tr.run_step()
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         losses = tr.run_step()
+    D.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return dict(metric="train images/sec (fwd + bwd + SGD step)", value=round(batch * steps / dt, 1), unit="images/sec",
-                ms_per_step=round(dt / steps * 1e3, 2), steps=steps, warmup=warmup,
-                config=dict(workload="configs/yolov3.yaml (20 classes, FREEZE_AT 2) 416x416 batch 64 bf16, synthetic targets",
-                            conv_tflops=round(187.357e9 * batch * steps / dt / 1e12, 1)),
-                finite_losses=bool(all(torch.isfinite(v) for v in losses.values())))
+    dt = D.max_over_ranks(time.perf_counter() - t0, model.device)
+    finite = bool(all(torch.isfinite(v) for v in losses.values()))
+    rec = dict(metric="train images/sec (fwd + bwd + gradient exchange + SGD step)",
+               value=round(world * batch * steps / dt, 1), unit="images/sec", n_gpus=world,
+               ms_per_step=round(dt / steps * 1e3, 2), steps=steps, warmup=warmup,
+               config=dict(workload="configs/yolov3.yaml (20 classes, FREEZE_AT 2) 416x416 bf16, synthetic targets, "
+                                    f"{batch} images per GPU",
+                           batch_per_gpu=batch, global_batch=batch * world,
+                           conv_tflops=round(187.357e9 * world * batch * steps / dt / 1e12, 1)),
+               finite_losses=finite)
+    if world > 1:
+        import torch.distributed as dist
+        # data-parallel invariant: identical starting weights + averaged gradients = identical weights on every rank
+        chk = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        rec["params_in_sync"] = bool(D.max_over_ranks(chk, model.device) == -D.max_over_ranks(-chk, model.device))
+        eng = model.backbone.train_engine()
+        bucketers = [P.bucketer for P in eng._plans.values() if getattr(P, "bucketer", None) is not None]
+        rec["exchange"] = bucketers[0].exchange if bucketers else None
+        rec["buckets_per_step"] = len(bucketers[0].launched) if bucketers else 0
+        rec["backend"] = dist.get_backend()
+        rec["n_ranks_" + ("rccl" if dist.get_backend() == "nccl" else dist.get_backend())] = dist.get_world_size()
+    return rec
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -460,6 +490,7 @@ def run_rank(args) -> None:
         elapsed = float(mine.item())
 
     total_steps = repeats * args.steps
+    out = None
     if rank == 0:
         out = {
             "metric": w.metric,
@@ -484,8 +515,16 @@ def run_rank(args) -> None:
             out["postproc"] = w.postproc()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = w.cpu_baseline()
-        if world == 1 and not args.no_train and hasattr(w, "train"):
-            out["train"] = w.train()
+        if dist is not None:
+            # ranks the collective backend really connected (RCCL when the backend is nccl)
+            out["n_ranks_" + ("rccl" if dist.get_backend() == "nccl" else dist.get_backend())] = dist.get_world_size()
+    # the secondary (training) measurement is collective when world > 1: every rank runs it (the others wait in its
+    # first collective while rank 0 finishes the records above), rank 0 reports it
+    if not args.no_train and hasattr(w, "train"):
+        train_rec = w.train()
+        if out is not None:
+            out["train"] = train_rec
+    if out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -33,6 +33,18 @@ class StubWorkload:
     def roofline(self):
         return {"bound": "hbm", "achieved": 0.0, "peak": 1.0, "unit": "GB/s", "frac": 0.0, "traffic": None}
 
+    def train(self):
+        """Collective like the real workload's: every rank takes part (an all-reduce over the job's process group)."""
+        import torch
+        import torch.distributed as dist
+        self.train_calls = getattr(self, "train_calls", 0) + 1
+        n = 1
+        if dist.is_available() and dist.is_initialized():
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            n = int(t.item())
+        return {"metric": "stub train", "value": 1.0, "n_gpus": n, "params_in_sync": True, "exchange": "allreduce"}
+
     def cpu_baseline(self):
         return {"value": 0.0, "unit": "steps/sec", "cores": 1, "kind": "port", "sample": "stub"}
 

@@ -32,6 +32,9 @@ def test_gpus_2_starts_two_ranks(capfd, monkeypatch):
     assert rec["timed_steps"] % 3 == 0 and rec["timed_steps"] >= 3
     assert rec["config"]["steps_run_on_rank0"] == 1 + 3 + rec["timed_steps"]
     assert "cpu_baseline" not in rec  # rank 0 at N = 1 only
+    # the training block is measured at N > 1 too, by all ranks together (its all-reduce saw both of them)
+    assert rec["train"]["n_gpus"] == 2 and rec["train"]["params_in_sync"] and rec["train"]["exchange"] == "allreduce"
+    assert rec["n_ranks_gloo"] == 2
 
 
 def test_gpus_1_is_one_process(capfd, monkeypatch):
@@ -40,6 +43,13 @@ def test_gpus_1_is_one_process(capfd, monkeypatch):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["timed_steps"] == 2 and len(rec["per_rank_value"]) == 1
     assert rec["cpu_baseline"]["kind"] == "port"
+    assert rec["train"]["n_gpus"] == 1
+
+
+def test_no_train_flag_skips_the_training_block(capfd, monkeypatch):
+    rc, lines = _run(capfd, monkeypatch, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--min-seconds", "0", "--no-train"])
+    assert rc == 0 and len(lines) == 1
+    assert "train" not in json.loads(lines[0])
 
 
 def test_a_failing_rank_fails_the_launch(monkeypatch, capfd):

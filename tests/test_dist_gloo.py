@@ -71,6 +71,7 @@ def _bucket_worker(rank, world, port, out):
     n = 1000
     arena = torch.arange(n, dtype=torch.float32) * (rank + 1)  # rank r holds (r+1) * i
     bk = D.GradBucketer(arena, bucket_bytes=300 * 4)
+    assert bk.mode == "auto" and bk.exchange == "allreduce" and not bk.direct   # the direct mesh exchange is an opt-in
     bk.start()
     for end in (100, 250, 320, 700, 990):   # "layers" finishing during backward
         bk.ready(end)

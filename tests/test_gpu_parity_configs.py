@@ -216,6 +216,16 @@ def test_chained_bf16_meets_5e_2_on_trained_weights(cuda):
         worst[name] = rel(out[name].float().cpu(), ref32[name])
     print("bf16 plan against the fp32 oracle on trained weights:", {k: round(v, 4) for k, v in worst.items()})
     assert max(worst.values()) < 5e-2, worst
+    # the same at the benchmark's input size (the network is fully convolutional): fresh 416 x 416 images of the same
+    # kind, heads within 5e-2 of the fp32 oracle
+    x416 = torch.stack([d["image"] for d in overfit_check.make_set(2, 416, model.num_classes, 6, "cpu")]).float() / 255.0
+    with torch.no_grad():
+        ref416 = R.fpn_forward(x416, sd)
+    out416 = model.backbone(x416.to(cuda))
+    torch.cuda.synchronize()
+    worst416 = {name: rel(out416[name].float().cpu(), ref416[name]) for name in ("p3", "p4", "p5")}
+    print("the same at 416 x 416:", {k: round(v, 4) for k, v in worst416.items()})
+    assert max(worst416.values()) < 5e-2, worst416
     # detections: bf16 HIP path against the fp32 oracle's inference()
     got = [_as_rows(r["instances"]) for r in model([dict(image=i) for i in imgs])]
     with torch.no_grad():

@@ -290,3 +290,10 @@ def test_reference_package_name_resolves_to_the_same_modules():
     assert yolo.modeling is yolo_amd.modeling
     with pytest.raises(ModuleNotFoundError):
         importlib.import_module("yolo.no_such_module")
+    # the aliased modules keep their own identity: importing them as ``yolo.X`` must not re-stamp the spec of
+    # ``yolo_amd.X`` (reload and relative imports inside functions depend on it)
+    for name in ("checkpoint", "modeling.backbone.fpn", "data.transforms"):
+        m = importlib.import_module("yolo_amd." + name)
+        assert m.__spec__.name == "yolo_amd." + name and m.__name__ == "yolo_amd." + name, (name, m.__spec__.name)
+        assert m.__package__ == m.__spec__.parent
+    importlib.reload(importlib.import_module("yolo_amd.modeling.box_regression"))

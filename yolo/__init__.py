@@ -14,14 +14,25 @@ import yolo_amd as _impl
 
 
 class _AliasLoader(importlib.abc.Loader):
+    """The import machinery stamps the spec it was given (name ``yolo.X``, this loader) on whatever module
+    ``create_module`` returns.  The module returned here is the live ``yolo_amd.X``, which must keep its own identity
+    (``__spec__``, ``__loader__``, ``__package__``: ``importlib.reload`` and relative imports inside functions depend
+    on them), so they are saved before the machinery touches the module and put back in ``exec_module``."""
+
+    _KEEP = ("__spec__", "__loader__", "__package__", "__name__", "__file__", "__path__", "__cached__")
+
     def __init__(self, target: str):
         self.target = target
+        self._own = {}
 
     def create_module(self, spec):
-        return importlib.import_module(self.target)   # the existing module object is the module
+        mod = importlib.import_module(self.target)    # the existing module object is the module
+        self._own = {k: getattr(mod, k) for k in self._KEEP if hasattr(mod, k)}
+        return mod
 
     def exec_module(self, module):                    # already executed under its own name
-        pass
+        for k, v in self._own.items():
+            setattr(module, k, v)
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):

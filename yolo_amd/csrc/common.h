@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/yolo_hip.h"
 
 namespace yolo {
@@ -52,6 +54,28 @@ inline ViewGeom geom_of(const yolo_view& v) {
 }
 
 inline size_t elem_size(int dtype) { return dtype == YOLO_BF16 ? 2 : 4; }
+
+// A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) is a property of the kernel ON ONE
+// DEVICE: it is raised once per device for the kernels of one call site, with that device current, whichever thread
+// launches there first.  One static DynLdsLimit per call site.
+struct DynLdsLimit {
+    std::mutex lock;
+    unsigned long long raised = 0;  // bit d: done on device d
+    hipError_t raise(const void* const* kernels, int n, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        std::lock_guard<std::mutex> g(lock);
+        if (raised & bit) return hipSuccess;
+        for (int i = 0; i < n; ++i) {
+            e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+        }
+        raised |= bit;
+        return hipSuccess;
+    }
+};
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);

@@ -826,13 +826,10 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, int copies = 1) 
     constexpr int LDS = LDS0;
 #endif
     auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D, STRIP>;
-    // the kernel's dynamic-LDS limit is raised once per instance (and process), whichever thread launches first
-    static std::once_flag attr_once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(attr_once, [&] {
-        attr_status = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    });
-    YOLO_CHECK_HIP(attr_status);
+    // the kernel's dynamic-LDS limit is raised once per instance and device
+    static DynLdsLimit lds_limit;
+    const void* const kerns[] = {(const void*)kern};
+    YOLO_CHECK_HIP(lds_limit.raise(kerns, 1, LDS));
     const int nblocks = p.n_ctiles * p.n_ptiles * copies;  // copies > 1: split-K (see the kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), LDS, stream, p);
     YOLO_CHECK_HIP(hipGetLastError());

@@ -1166,13 +1166,10 @@ extern "C" int yolo_batched_nms(const float* boxes, const float* scores, const i
     p.keep_stride = keep_stride;
     p.n_keep = n_keep;
 
-    static std::once_flag attr_once;  // the sort kernel's tables and its reordered tile: 70 KiB of dynamic LDS
-    static hipError_t attr_status = hipSuccess;
+    static DynLdsLimit lds_limit;  // the sort kernel's tables and its reordered tile: 70 KiB of dynamic LDS
     constexpr int SORT_LDS = (int)sizeof(SortShared);
-    std::call_once(attr_once, [&] {
-        attr_status = hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS);
-    });
-    YOLO_CHECK_HIP(attr_status);
+    const void* const sort_kern[] = {(const void*)nms_sort_kernel};
+    YOLO_CHECK_HIP(lds_limit.raise(sort_kern, 1, SORT_LDS));
     YOLO_CHECK_HIP(hipMemsetAsync(p.nseg, 0, 256, st));
     hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(SORT_THREADS), SORT_LDS, st, p);
     // one wave per segment; at most N * num_classes segments, and no more than candidates

@@ -586,18 +586,11 @@ extern "C" int yolo_conv2d_wgrad(const yolo_view* x, const yolo_view* dz, int N,
     p.out = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     constexpr int LDS = 2 * 2 * 64 * 256;
-    static std::once_flag attr_once;  // dynamic-LDS limit of the six instances, raised once per process
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(attr_once, [&] {
-        const void* kerns[] = {(const void*)wgrad_kernel<false, 0>, (const void*)wgrad_kernel<true, 0>,
-                               (const void*)wgrad_kernel<false, 1>, (const void*)wgrad_kernel<true, 1>,
-                               (const void*)wgrad_kernel<false, 2>, (const void*)wgrad_kernel<true, 2>};
-        for (const void* k : kerns) {
-            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) attr_status = e;
-        }
-    });
-    YOLO_CHECK_HIP(attr_status);
+    static DynLdsLimit lds_limit;  // dynamic-LDS limit of the six instances, raised once per device
+    const void* const kerns[] = {(const void*)wgrad_kernel<false, 0>, (const void*)wgrad_kernel<true, 0>,
+                                 (const void*)wgrad_kernel<false, 1>, (const void*)wgrad_kernel<true, 1>,
+                                 (const void*)wgrad_kernel<false, 2>, (const void*)wgrad_kernel<true, 2>};
+    YOLO_CHECK_HIP(lds_limit.raise(kerns, 6, LDS));
     const int blocks = p.n_mt * p.n_nt * p.taps * p.splits;
     const bool narrow = Cin <= 64;
     auto kern = mode == 1 ? (narrow ? wgrad_kernel<true, 1> : wgrad_kernel<false, 1>)

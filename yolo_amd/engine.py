@@ -66,6 +66,10 @@ class InFlight:
     event: "torch.cuda.Event"
     score_thr: float
     geom: Tuple[int, int, int]  # N, stored image height, width
+    # finish(record_count=True): the batch's candidate total, copied into pinned host memory behind the decode, and the
+    # event that says the copy has landed (the throughput mode checks for overflow without making the host wait)
+    count_host: Optional[torch.Tensor] = None
+    count_event: Optional["torch.cuda.Event"] = None
 
 
 @dataclass
@@ -78,6 +82,7 @@ class _GraphedDetect:
     n_det: torch.Tensor
     in_flight: InFlight
     sizes: tuple
+    buffers: tuple = ()   # keep / n_keep / NMS workspace the captured launches write: alive as long as the graph
 
 
 class Yolov3Engine:
@@ -114,6 +119,8 @@ class Yolov3Engine:
         # detect_graphed(): call signature -> captured HIP graph of one detect() with its static input and outputs
         self._graphs: Dict[tuple, "_GraphedDetect"] = {}
         self._graph_seen: Dict[tuple, int] = {}
+        self.last_in_flight: Optional[InFlight] = None
+        self._count_host: Dict[int, torch.Tensor] = {}   # id(plan) -> pinned word for the candidate total
         self.repack()
 
     # ------------------------------------------------------------------ weights
@@ -298,6 +305,7 @@ class Yolov3Engine:
             cap = max(P.cand_cap, P.N * 4096)
         if P.cand is None or P.cand.scores.numel() < cap:
             dev = self.device
+            self._drop_graphs_of(P)   # captured launches of this plan write the old candidate buffers
             P.cand = ops.Candidates(torch.empty((cap, 4), dtype=torch.float32, device=dev),
                                     torch.empty((cap,), dtype=torch.float32, device=dev),
                                     torch.empty((cap,), dtype=torch.int32, device=dev),
@@ -333,11 +341,14 @@ class Yolov3Engine:
 
     @ops.on_own_device
     def finish(self, h: "InFlight", *, nms_thr: float, max_det: int = 100, nms_mode: int = ops.NMS_AUTO,
-               auto_limit: int = 20000, in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None):
+               auto_limit: int = 20000, in_hw: Optional[torch.Tensor] = None, out_hw: Optional[torch.Tensor] = None,
+               record_count: bool = False):
         """Second half of detect(): enqueue batched NMS + top-k gather behind the batch's decode.  The candidate
         counts stay on the device (the NMS reads them there), so nothing is read back and the host never waits.
         Returns (det [N, max_det, 6], n_det [N]).  A batch with more candidates than the candidate buffers hold is
-        processed on the first ``capacity`` of them; ``overflowed(h)`` tells (it reads one word back)."""
+        processed on the first ``capacity`` of them; ``overflowed(h)`` tells (it reads one word back), and with
+        ``record_count`` the total is also copied to pinned host memory behind the decode (``h.count_host`` is valid
+        once ``h.count_event`` has completed) so that a caller can check later without waiting now."""
         P, cand = h.plan, h.cand
         cap = cand.scores.numel()
         dev = self.device
@@ -351,11 +362,23 @@ class Yolov3Engine:
             side.wait_event(h.event)
         with torch.cuda.stream(side):
             t0 = self._trace_begin()
+            if record_count:
+                word = self._count_host.get(id(P))
+                if word is None:
+                    if len(self._count_host) > 64:
+                        self._count_host.clear()
+                    word = self._count_host[id(P)] = torch.zeros(1, dtype=torch.int32).pin_memory()
+                word.copy_(cand.img_offsets[P.N:P.N + 1], non_blocking=True)
+                h.count_host = word
+                h.count_event = torch.cuda.Event()
+                h.count_event.record()
             if P.keep is None or P.keep.shape[1] != max_det:
+                self._drop_graphs_of(P)   # captured launches of this plan write the old keep buffers
                 P.keep = torch.empty((P.N, max_det), dtype=torch.int32, device=dev)
                 P.n_keep = torch.empty((P.N,), dtype=torch.int32, device=dev)
             need = ops.nms_workspace_bytes(P.N, cap)
             if P.nms_ws is None or P.nms_ws.numel() < need:
+                self._drop_graphs_of(P)
                 P.nms_ws = torch.empty(need, dtype=torch.uint8, device=dev)
             ops.batched_nms(cand.boxes, cand.scores, cand.classes, cand.img_offsets, cap, nms_thr,
                             num_classes=self.num_classes, mode=nms_mode, auto_limit=auto_limit, top_k=max_det,
@@ -383,10 +406,15 @@ class Yolov3Engine:
         over = self.overflowed(h) if total is None else max(0, int(total) - h.cand.scores.numel())
         if over:
             h.plan.cand_cap = int((h.cand.scores.numel() + over) * 1.25) + 1024
-            # captured graphs of this plan hold the old candidate buffers
-            for key in [k for k, g in self._graphs.items() if g.in_flight.plan is h.plan]:
-                del self._graphs[key]
+            self._drop_graphs_of(h.plan)   # captured graphs of this plan hold the old candidate buffers
         return over > 0
+
+    def _drop_graphs_of(self, P: Plan) -> None:
+        """Forget the captured detect() calls that run on plan ``P``: their launches hold raw pointers of its buffers."""
+        if torch.cuda.is_current_stream_capturing():
+            return   # the capture in progress is not in the table yet; it was preceded by an eager call on this plan
+        for key in [k for k, g in self._graphs.items() if g.in_flight.plan is P]:
+            del self._graphs[key]
 
     def overflowed(self, h: "InFlight") -> int:
         """Candidates the batch produced beyond the capacity of its candidate buffers (0 = none were dropped).
@@ -474,7 +502,9 @@ class Yolov3Engine:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 det, n_det = self.detect(static_in, **kw)
-            g = _GraphedDetect(graph, static_in, det, n_det, self.last_in_flight, (in_hw, out_hw))
+            P = self.last_in_flight.plan
+            g = _GraphedDetect(graph, static_in, det, n_det, self.last_in_flight, (in_hw, out_hw),
+                               (P.keep, P.n_keep, P.nms_ws, P.decode_ws))
             while len(self._graphs) >= self.GRAPH_KEEP:
                 self._graphs.pop(next(iter(self._graphs)))
         self._graphs[key] = g   # most recently used last
@@ -485,15 +515,43 @@ class Yolov3Engine:
 
     def detect_pipelined(self, batches, *, score_thr: float, nms_thr: float, mean, std, max_det: int = 100,
                          nms_mode: int = ops.NMS_AUTO, auto_limit: int = 20000, depth: int = 2):
-        """Throughput mode over an iterable of image batches: batch i+1's convolutions are queued before the
-        host waits for batch i's candidate count, so the GPU never idles on that read-back.  Yields
-        (det, n_det) per batch, in order; results of a batch are valid until ``depth`` more batches are submitted."""
-        pending: List[InFlight] = []
+        """Throughput mode over an iterable of image batches: batch i+1's convolutions are queued before batch i's
+        NMS, on alternating sets of buffers, and the host never waits for the GPU.  Yields (det, n_det) per batch, in
+        order.
+
+        Candidate overflow: a batch's candidate total is copied to pinned host memory behind its decode and looked at
+        one batch later (when the copy has long landed), BEFORE the batch's result is yielded -- results therefore leave
+        one batch later than they are finished.  A batch that produced more candidates than its buffers hold (its NMS
+        then saw only the first ``capacity`` of them: the last images of the batch lose detections) is run again on
+        enlarged buffers of a plan of its own, and the enlarged capacity is kept for the batches that follow."""
+        pending: List[Tuple[InFlight, torch.Tensor]] = []            # submitted, NMS not queued yet
+        done: List[Tuple[InFlight, torch.Tensor, tuple]] = []        # NMS queued, candidate total not looked at yet
+        kw = dict(nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode, auto_limit=auto_limit)
+
+        def settle(rec):
+            h, images, out = rec
+            h.count_event.synchronize()   # recorded a whole batch ago
+            total = int(h.count_host.item())
+            if total <= h.cand.scores.numel():
+                return out
+            # rare: run the batch again, alone, on a plan nothing in flight uses, with room for what it produced
+            redo = self.plan(h.plan.N, h.plan.H, h.plan.W, depth)
+            redo.cand_cap = max(redo.cand_cap, int(total * 1.25) + 1024)
+            for s in range(depth):         # later batches of this shape start with the larger buffers too
+                P = self.plan(h.plan.N, h.plan.H, h.plan.W, s)
+                P.cand_cap = max(P.cand_cap, redo.cand_cap)
+            h2 = self.submit(images, score_thr=score_thr, mean=mean, std=std, slot=depth)
+            return self.finish(h2, **kw)
+
         for i, images in enumerate(batches):
-            pending.append(self.submit(images, score_thr=score_thr, mean=mean, std=std, slot=i % depth))
+            pending.append((self.submit(images, score_thr=score_thr, mean=mean, std=std, slot=i % depth), images))
             if len(pending) == depth:
-                yield self.finish(pending.pop(0), nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode,
-                                  auto_limit=auto_limit)
+                h, im = pending.pop(0)
+                done.append((h, im, self.finish(h, record_count=True, **kw)))
+            if len(done) == 2:
+                yield settle(done.pop(0))
         while pending:
-            yield self.finish(pending.pop(0), nms_thr=nms_thr, max_det=max_det, nms_mode=nms_mode,
-                              auto_limit=auto_limit)
+            h, im = pending.pop(0)
+            done.append((h, im, self.finish(h, record_count=True, **kw)))
+        while done:
+            yield settle(done.pop(0))

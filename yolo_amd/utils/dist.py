@@ -124,7 +124,15 @@ class GradBucketer:
       Every element is summed by exactly one rank, so all ranks end with bit-identical gradients.  The exchange runs
       on a stream of its own; a remainder of fewer than ``world`` elements at the arena's end goes out as a small
       all-reduce.
-    * ``auto`` (default): direct on the nccl (= RCCL) backend from 3 ranks on, all-reduce otherwise.
+    * ``auto`` (default): all-reduce.  The direct exchange has only run over gloo host copies so far; it stays an
+      opt-in (YOLO_GRAD_EXCHANGE=direct) until one multi-GPU run on RCCL has shown bit-identical gradients and no
+      stall, then ``auto`` may pick it from 3 ranks on.
+
+    A GPU arena on the gloo backend (several ranks sharing one card: a rehearsal of the control flow, never
+    production) goes through host copies.  Those copies block the host, so they are NOT made from inside the backward
+    loop -- there the caller is inside its weight-gradient stream's context, and a host thread parked in a device-to-host
+    copy behind that stream cannot queue the rest of the backward pass while its peers wait for it in the host-side
+    collective.  ``ready()`` only notes the range; ``finish()`` exchanges all of them behind the backward pass.
     """
 
     def __init__(self, arena: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, mode: Optional[str] = None):
@@ -146,9 +154,12 @@ class GradBucketer:
 
     @property
     def direct(self) -> bool:
-        if self.world < 2 or self.mode == "allreduce":
-            return False
-        return self.mode == "direct" or (self.world > 2 and dist.get_backend(self.group) == "nccl")
+        return self.world >= 2 and self.mode == "direct"
+
+    @property
+    def exchange(self) -> str:
+        """The exchange this bucketer runs: "allreduce" or "direct"."""
+        return "direct" if self.direct else "allreduce"
 
     def start(self) -> None:
         self.sent, self.works, self.launched = 0, [], []
@@ -223,10 +234,17 @@ class GradBucketer:
         self.sent = end
 
     def ready(self, end: int) -> None:
+        if self.world > 1 and _host_staged(self.arena, self.group):
+            return   # host-staged rehearsal: every range goes out from finish(), see the class comment
         if end - self.sent >= self.bucket:
             self._launch(end)
 
     def finish(self) -> None:
+        if self.world > 1 and _host_staged(self.arena, self.group):
+            # the same bucket boundaries as the overlapped form, one after the other, on the caller's stream
+            n = self.arena.numel()
+            while n - self.sent > self.bucket:
+                self._launch(self.sent + self.bucket)
         self._launch(self.arena.numel(), flush=True)
         for w in self.works:
             w.wait()
