@@ -134,6 +134,51 @@ def test_conv_strip_form(cuda, shape):
     assert bool((full[..., keep] == 7.0).all())
 
 
+# (Cin, Cout, k, stride, N, H_in, W_in, residual, y halo, y channel offset / total): launches that take the 128 x 176 tile
+# (11 pixel fragment columns, the last one shared by the two pixel-waves) -- enough pixels that the tile count decides:
+# ragged last tile, tiles spanning rows and images, residual (two uneven f32 staging halves) and plain (bf16 staging),
+# stride 2, 1x1, two channel tiles, output into a channel slice without halo.
+ODD_TILE_SHAPES = [
+    (64, 128, 3, 1, 87, 32, 32, True, 1, (0, 128)), (64, 128, 3, 1, 87, 32, 32, False, 0, (128, 384)),
+    (128, 256, 1, 1, 4, 106, 106, False, 1, (0, 256)), (64, 128, 3, 2, 87, 64, 64, False, 1, (0, 128)),
+    (128, 256, 1, 1, 4, 106, 106, True, 1, (0, 256)),
+]
+
+
+@pytest.mark.parametrize("shape", ODD_TILE_SHAPES, ids=lambda s: "x".join(map(str, s[:8])))
+def test_conv_176_pixel_tile(cuda, shape):
+    from yolo_amd import ops
+    cin, cout, k, stride, N, H, W, use_res, yhalo, (choff, chtot) = shape
+    g = torch.Generator().manual_seed(cin + 5 * k + stride)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    norm = _rand_norm(cout, g)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(N, cout, Ho, Wo, generator=g) if use_res else None
+    wf, bf = ops.fold_norm(w, None, norm)
+    ref = _ref_conv(x.bfloat16().float(), wf.bfloat16().float(), None, bf, stride, 0.1,
+                    res.bfloat16().float() if use_res else None)
+    wp, bp = ops.pack_conv(wf, bf, torch.bfloat16, cuda)
+    xv = ops.view_from_nchw(x.to(cuda), 1, torch.bfloat16)
+    ybuf = ops.alloc_view(N, Ho, Wo, chtot, yhalo, torch.bfloat16, cuda)
+    ybuf.buf.fill_(7.0)
+    yv = ybuf.slice(choff, cout)
+    rv = ops.view_from_nchw(res.to(cuda), 0, torch.bfloat16) if use_res else None
+    assert ",176," in ops.conv_kernel_name(xv, yv, cin, cout, k, stride), ops.conv_kernel_name(xv, yv, cin, cout, k, stride)
+    ops.conv2d_fwd(xv, wp, bp, yv, cin=cin, cout=cout, k=k, stride=stride, residual=rv)
+    torch.cuda.synchronize()
+    got = yv.nchw()[:, :cout].float().cpu()
+    assert _rel_err(got, ref) < BF16_TOL
+    assert float((got - ref).abs().mean() / ref.abs().mean()) < 4e-3
+    full = ybuf.buf.float().cpu()
+    if yhalo:
+        assert bool((full[:, 0] == 7.0).all() and (full[:, -1] == 7.0).all())
+        assert bool((full[:, :, 0] == 7.0).all() and (full[:, :, -1] == 7.0).all())
+    keep = torch.ones(chtot, dtype=torch.bool)
+    keep[choff:choff + cout] = False
+    assert bool((full[..., keep] == 7.0).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_concat_slice_and_upsample(cuda, dtype):
     """UpSampleBlock + torch.cat (fpn.py:33-37,179): conv output written 2x-upsampled into channels

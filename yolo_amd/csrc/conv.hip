@@ -134,20 +134,35 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // three k-steps instead of 3 * (TC + TP) * 128.  Outputs at the halo columns (2 of W + 2) are computed and dropped.
 // The k order is (kh, channel chunk, kw); the weights stay packed (kh, kw, channel).  p.Ho / p.Wo / p.M describe the
 // position grid (H, W + 2, N * H * (W + 2)); p.Wreal is W.
+//
+// ODD: a pixel tile with an ODD number NF of 16-pixel fragment columns (TP = 176: 11) on the 2 x 2 wave layout.  A 128 x 192
+// tile needs 57 pixel tiles for the 64 x 13 x 13 pixels of a stride-32 layer (456 workgroups for 512 resident slots) and 226
+// for a stride-16 layer (904 for 1024); with 176 pixels it is 62 (496) and 246 (984): the rounds are full.  Both
+// pixel-waves of a channel half take (NF - 1) / 2 columns of their own -- interleaved, column 2j + wp, so that the
+// first and the second half of the tile's columns each hold columns of both waves -- and SHARE the last column: wave
+// wp computes channel fragments 2wp, 2wp + 1 of it.  Every wave then issues the same 22 MFMAs per 32 k (balanced, which
+// an uneven 6 + 5 split of columns is not).  So that the shared column's two fragments have compile-time register
+// indices in both waves, wave wp keeps channel fragment f in slot f ^ 2wp: slots 0 and 1 are always the shared ones.
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
-          bool STRIP = false>
+          bool STRIP = false, bool ODD = false>
 __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(const ConvParams p) {
     static_assert(!(S2D && (TAP2 || STATS)), "S2D is a plain bf16/f32 convolution");
     static_assert(!(STRIP && (TAP2 || S2D || STATS || sizeof(T) != 2)), "STRIP is a plain bf16 3x3 convolution");
     static_assert(WC * WP == NW, "waves");
+    static_assert(!ODD || (sizeof(T) == 2 && TC == 128 && WC == 2 && WP == 2 && NW == 4 && (TP / 16) % 2 == 1 && TP % 16 == 0 &&
+                           !TAP2 && !STATS && !S2D && !STRIP),
+                  "ODD is a plain bf16 convolution on 2 x 2 waves with an odd number of pixel fragment columns");
     constexpr bool BF = sizeof(T) == 2;
+    constexpr int NF = TP / 16;  // pixel fragment columns of the tile
     constexpr int SP = (TP + 2 + 7) / 8;          // STRIP: 1-KiB pieces (8 pixel rows) of a strip
     constexpr int NXS = (SP + NW - 1) / NW;       // STRIP: strip pieces per wave
     constexpr int XS_BYTES = SP * 1024;
     constexpr int W_BYTES = TC * ROWB, X_BYTES = STRIP ? XS_BYTES : TP * ROWB, BUF = W_BYTES + X_BYTES;
-    constexpr int FC = TC / (16 * WC), FP = TP / (16 * WP);
-    constexpr int NWP = TC / (8 * NW), NXP = TP / (8 * NW);  // 1-KiB pieces per wave per operand
-    static_assert(TC % (8 * NW) == 0 && TP % (8 * NW) == 0, "whole pieces per wave");
+    constexpr int FC = TC / (16 * WC), FP = ODD ? (NF - 1) / 2 : TP / (16 * WP);  // FP: a wave's own pixel columns
+    constexpr int XPIECES = TP / 8;                                   // 1-KiB pieces (8 pixel rows) of the pixel operand
+    constexpr int NWP = TC / (8 * NW), NXP = (XPIECES + NW - 1) / NW;  // pieces per wave per operand
+    constexpr bool XEVEN = XPIECES % NW == 0;                         // else the last round of pieces is partial
+    static_assert(TC % (8 * NW) == 0 && TP % 8 == 0 && (ODD || XEVEN), "whole pieces per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -277,7 +292,8 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #pragma unroll
         for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + NW * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < NXP; ++i) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + NW * i) * 1024);
+        for (int i = 0; i < NXP; ++i)
+            if (XEVEN || wave + NW * i < XPIECES) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + NW * i) * 1024);
         ++cur_step;
         if (++cur_cc == p.cpt) {
             cur_cc = 0;
@@ -308,18 +324,27 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     const int wc = wave / WP, wp = wave % WP;
     const int l15 = lane & 15, q = lane >> 4, l7 = lane & 7;
     const int a_base = (wc * (TC / WC) + l15) * ROWB;            // + fc*16*ROWB
-    const int b_base = W_BYTES + (wp * (TP / WP) + l15) * ROWB;  // + fp*16*ROWB
+    // pixel columns of a wave: contiguous (column wp * FP + j), ODD: interleaved (column 2j + wp) + the shared last one
+    constexpr int BSTEP = ODD ? 32 : 16;                         // tile rows between a wave's consecutive columns
+    const int b_base = W_BYTES + ((ODD ? wp * 16 : wp * (TP / WP)) + l15) * ROWB;  // + j*BSTEP*ROWB
+    [[maybe_unused]] const int bs_base = W_BYTES + ((NF - 1) * 16 + l15) * ROWB;  // ODD: the shared column
     const int ko0 = (q ^ l7) << 4;                               // k chunk q, swizzled
     const int ko1 = ko0 ^ 64;                                    // k chunk 4+q
+    // channel fragment held in accumulator slot i of this wave (ODD: slot i = fragment i ^ 2wp), as a tile-row offset
+    auto frag_of_slot = [&](int i) { return ODD ? (i ^ (2 * wp)) : i; };
+    [[maybe_unused]] const int a_sw = ODD ? 2 * wp * 16 * ROWB : 0;  // ODD: slots 0,1 / 2,3 swap places when wp = 1
+    auto a_off = [&](int i) { return ODD ? a_base + ((i * 16 * ROWB) ^ a_sw) : a_base + i * 16 * ROWB; };
 
-    // accumulators start from the bias (lane holds channels ch0 + 16*i + 0..3 of pixel column l15)
+    // accumulators start from the bias (lane holds channels ch0 + 16*frag + 0..3 of pixel column l15)
     f32x4 acc[FC][FP];
+    [[maybe_unused]] f32x4 acc_sh[2];  // ODD: slots 0, 1 of the shared column
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
-        f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + wc * (TC / WC) + q * 4 + i * 16);
+        f32x4 bv = *(const f32x4*)(p.bias + tile_c * TC + wc * (TC / WC) + q * 4 + frag_of_slot(i) * 16);
         if (p.split_steps) bv = f32x4{0.f, 0.f, 0.f, 0.f};  // partial sums: the bias is added once, by the reduction
 #pragma unroll
         for (int j = 0; j < FP; ++j) acc[i][j] = bv;
+        if (ODD && i < 2) acc_sh[i] = bv;
     }
 
     // All fragment reads of a k-step (2 sub-steps of 32 k) are issued up front; the second half lands
@@ -354,23 +379,30 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     auto compute = [&](const char* buf) {
         if constexpr (BF) {
             bf16x8 a[2][FC], b[2][FP];
+            [[maybe_unused]] bf16x8 bsh[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ko = kk ? ko1 : ko0;
 #pragma unroll
-                for (int i = 0; i < FC; ++i) a[kk][i] = *(const bf16x8*)(buf + a_base + i * 16 * ROWB + ko);
+                for (int i = 0; i < FC; ++i) a[kk][i] = *(const bf16x8*)(buf + a_off(i) + ko);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(buf + b_base + j * 16 * ROWB + ko);
+                for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(buf + b_base + j * BSTEP * ROWB + ko);
+                if constexpr (ODD) bsh[kk] = *(const bf16x8*)(buf + bs_base + ko);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMA block
             __builtin_amdgcn_s_setprio(1);  // matrix work first when both co-resident workgroups have some (+1.5-2 %)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
                 for (int i = 0; i < FC; ++i)
 #pragma unroll
                     for (int j = 0; j < FP; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+                if constexpr (ODD) {
+                    acc_sh[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][0], bsh[kk], acc_sh[0], 0, 0, 0);
+                    acc_sh[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][1], bsh[kk], acc_sh[1], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
         } else {
             // f32 MFMA 16x16x4 takes ONE k per lane group; element e of each lane's 16-byte chunk feeds
@@ -469,7 +501,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     constexpr int HP = TP / NH;
     constexpr int G = TC / 8;       // 8-channel groups per pixel
     constexpr int PPP = NW * 64 / G;  // pixels per pass
-    static_assert(HP % PPP == 0, "whole passes");
+    static_assert(ODD || HP % PPP == 0, "whole passes");
     const int g = tid % G;
     const int ch_first = tile_c * TC + g * 8;
     int prow = tid / G;  // this lane's pixel row inside a pass
@@ -483,7 +515,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     // none waits), so a half holds two runs of HP/2 tile pixels, HP/2 apart: staged row s is tile pixel
     // half * HP/2 + s (+ HP/2 from the second run on).  JUMP = that extra distance, met once per lane and half.
     constexpr int RUN = NH == 2 ? HP / 2 : HP, JUMP = NH == 2 ? HP / 2 : 0;
-    static_assert(RUN % PPP == 0 && (NH == 1 || FP % 2 == 0), "runs of whole passes");
+    static_assert(ODD || (RUN % PPP == 0 && (NH == 1 || FP % 2 == 0)), "runs of whole passes");
     const int adv_rows = PPP / p.Wo, adv_cols = PPP - adv_rows * p.Wo;  // PPP pixels = adv_rows rows + adv_cols columns
     const int jmp_rows = (PPP + JUMP) / p.Wo, jmp_cols = (PPP + JUMP) - jmp_rows * p.Wo;
     const bool tiny = jmp_rows + 1 > p.Ho;
@@ -491,24 +523,28 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     //      -- half the LDS bytes, and a 128 x 192 tile (48 KB) goes through in ONE piece instead of two halves: one
     //      barrier pair less.  Same values as the f32-staged path (LeakyReLU in f32, one rounding).
     if constexpr (BF && TC == 128 && !STATS && !TAP2 && !STRIP) {
-        if (!p.res && !p.y_f32 && !p.upsample && !p.split_steps && adv_rows + 1 <= p.Ho) {
+        // (the ODD instance is only launched for bf16 output without upsample or split-K on images of at least a step)
+        if (!p.res && (ODD || (!p.y_f32 && !p.upsample && !p.split_steps && adv_rows + 1 <= p.Ho))) {
             constexpr int NPB = TP / PPP;
             __syncthreads();  // every wave is done with the operand buffers
             {
                 const int ch0 = wc * (TC / WC) + q * 4;
-                const int px0 = wp * (TP / WP) + l15;
+                const int px0 = (ODD ? wp * 16 : wp * (TP / WP)) + l15;
+                auto put = [&](const f32x4 a, int ch, int px) {
+                    const f32x4 v = leaky4(a, p.slope);
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(v[0], v[1]);
+                    pk[1] = pack_bf16x2(v[2], v[3]);
+                    // pixel row = 256 bytes; 16-byte chunk c of pixel px sits at chunk c ^ (px & 15)
+                    *(u32x2*)(smem + px * 256 + ((((ch >> 3) ^ px) & 15) << 4) + ((ch >> 2) & 1) * 8) = pk;
+                };
 #pragma unroll
                 for (int i = 0; i < FC; ++i) {
-                    const int ch = ch0 + i * 16;
+                    const int ch = ch0 + frag_of_slot(i) * 16;
 #pragma unroll
-                    for (int j = 0; j < FP; ++j) {
-                        const int px = px0 + j * 16;
-                        const f32x4 v = leaky4(acc[i][j], p.slope);
-                        u32x2 pk;
-                        pk[0] = pack_bf16x2(v[0], v[1]);
-                        pk[1] = pack_bf16x2(v[2], v[3]);
-                        // pixel row = 256 bytes; 16-byte chunk c of pixel px sits at chunk c ^ (px & 15)
-                        *(u32x2*)(smem + px * 256 + ((((ch >> 3) ^ px) & 15) << 4) + ((ch >> 2) & 1) * 8) = pk;
+                    for (int j = 0; j < FP; ++j) put(acc[i][j], ch, px0 + j * BSTEP);
+                    if constexpr (ODD) {
+                        if (i < 2) put(acc_sh[i], ch, (NF - 1) * 16 + l15);
                     }
                 }
             }
@@ -558,6 +594,102 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 #endif
             return;
         }
+    }
+    // ---- ODD, with residual: f32 staging in two uneven halves, fragment columns [0, C0) and [C0, NF) -- each holds
+    //      columns of both pixel-waves (interleaved assignment), the second also the shared column; staged row s of
+    //      half h is tile pixel h * C0 * 16 + s.  Straight-line passes as in the generic path's `fast` form.
+    if constexpr (ODD) {
+        constexpr int J0 = (FP + 1) / 2, C0 = 2 * J0;  // own columns j < J0 of both waves = tile columns [0, C0)
+        auto run_half = [&](auto half_c) {
+            constexpr int HALF = decltype(half_c)::value;
+            constexpr int COLS = HALF == 0 ? C0 : NF - C0;
+            constexpr int NPH = COLS * 16 / PPP;
+            static_assert(COLS * 16 % PPP == 0 && COLS * 16 * TC * 4 <= 2 * BUF, "ODD epilogue half");
+            const int m0 = pix_base + HALF * C0 * 16 + prow;
+            int n0, ho0, wo0;
+            split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n0, ho0, wo0);
+            auto step = [&](int& n, int& ho, int& wo) {
+                wo += adv_cols;
+                ho += adv_rows;
+                if (wo >= p.Wo) {
+                    wo -= p.Wo;
+                    ++ho;
+                }
+                if (ho >= p.Ho) {
+                    ho -= p.Ho;
+                    ++n;
+                }
+            };
+            u32x4 rres[NPH];
+            if (ch_first < p.Cout) {
+                int n = n0, ho = ho0, wo = wo0;
+                const long long ro_first = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                           wo * p.r_pix_stride + (long long)ch_first * 2;
+#pragma unroll
+                for (int pass = 0; pass < NPH; ++pass) {
+                    const long long ro = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                         wo * p.r_pix_stride + (long long)ch_first * 2;
+                    rres[pass] = *(const u32x4*)(p.res + (m0 + pass * PPP < pix_end ? ro : ro_first));
+                    if (pass + 1 < NPH) step(n, ho, wo);
+                }
+            }
+            __syncthreads();
+            {
+                const int ch0 = wc * (TC / WC) + q * 4;
+                auto put = [&](const f32x4 a, int ch, int px) {  // px: staged row
+                    *(f32x4*)(smem + px * (TC * 4) + (((ch >> 2) ^ (px & 7)) << 4)) = leaky4(a, p.slope);
+                };
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const int ch = ch0 + frag_of_slot(i) * 16;
+#pragma unroll
+                    for (int j = HALF == 0 ? 0 : J0; j < (HALF == 0 ? J0 : FP); ++j)
+                        put(acc[i][j], ch, (2 * j + wp) * 16 + l15 - HALF * C0 * 16);
+                    if (HALF == 1 && i < 2) put(acc_sh[i], ch, (NF - 1 - C0) * 16 + l15);
+                }
+            }
+            __syncthreads();
+            TRACE_MARK(5 + 2 * HALF);
+            f32x4 sv0[NPH], sv1[NPH];
+#pragma unroll
+            for (int pass = 0; pass < NPH; ++pass) {
+                const int px = pass * PPP + prow;
+                const char* sp = smem + px * (TC * 4);
+                sv0[pass] = *(const f32x4*)(sp + (((2 * g) ^ (px & 7)) << 4));
+                sv1[pass] = *(const f32x4*)(sp + (((2 * g + 1) ^ (px & 7)) << 4));
+            }
+            int n = n0, ho = ho0, wo = wo0;
+#pragma unroll
+            for (int pass = 0; pass < NPH; ++pass) {
+                const bool lv = m0 + pass * PPP < pix_end && ch_first < p.Cout;
+                f32x4 v0 = sv0[pass], v1 = sv1[pass];
+                const u32x4 r = rres[pass];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    v0[2 * e] += __uint_as_float(r[e] << 16);
+                    v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                    v1[2 * e] += __uint_as_float(r[2 + e] << 16);
+                    v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
+                }
+                u32x4 packed;
+                packed[0] = pack_bf16x2(v0[0], v0[1]);
+                packed[1] = pack_bf16x2(v0[2], v0[3]);
+                packed[2] = pack_bf16x2(v1[0], v1[1]);
+                packed[3] = pack_bf16x2(v1[2], v1[3]);
+                char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)ho * p.y_row_stride +
+                           wo * p.y_pix_stride + (size_t)ch_first * 2;
+                if (lv) *(u32x4*)yp = packed;
+                if (pass + 1 < NPH) step(n, ho, wo);
+            }
+            TRACE_MARK(6 + 2 * HALF);
+        };
+        run_half(std::integral_constant<int, 0>{});
+        run_half(std::integral_constant<int, 1>{});
+#ifdef YOLO_CONV_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE_MARK(3);
+#endif
+        return;
     }
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
@@ -813,7 +945,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
 }
 
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
-          bool STRIP = false>
+          bool STRIP = false, bool ODD = false>
 static int launch_conv(const ConvParams& p, hipStream_t stream, int copies = 1) {
     // two operand buffers, or the f32 epilogue staging tile if that is larger (STRIP: two weight buffers + two strips
     // of ceil((TP + 2) / 8) KiB, and the staging tile whole)
@@ -825,7 +957,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, int copies = 1) 
 #else
     constexpr int LDS = LDS0;
 #endif
-    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D, STRIP>;
+    auto kern = conv_igemm_kernel<T, TC, TP, WC, WP, TAP2, NW, STATS, S2D, STRIP, ODD>;
     // the kernel's dynamic-LDS limit is raised once per instance and device
     static DynLdsLimit lds_limit;
     const void* const kerns[] = {(const void*)kern};
@@ -868,10 +1000,18 @@ static int launch_conv_copies(const ConvParams& p, int copies, hipStream_t strea
 // (measured 5-12 % faster per pixel); the 64-pixel tile moves the weights once per 64 pixels and pays the per-tile
 // set-up three times as often (measured ~1.5 x the cost per pixel), but fills the chip on layers with few pixels;
 // it is only considered for 1x1 layers with K <= 512, where nothing else does.
-static int pick_tp(int M, int n_ctiles, int nsteps) {
+//
+// The 176-pixel tile (11 fragment columns, the last shared by the two pixel-waves: see the kernel) costs 9 % more LDS
+// reads per multiply than the 192-pixel tile; it exists for the layers whose tile count it brings under a whole number
+// of rounds (64 images of 13 x 13 or 26 x 26 pixels: 496 / 984 tiles instead of 456 / 904 larger ones).  Only offered
+// (`odd_ok`) to launches its epilogue handles: bf16 in and out, no upsample, no BatchNorm sums, no split-K.
+#ifndef YOLO_TP176_COST
+#define YOLO_TP176_COST 96
+#endif
+static int pick_tp(int M, int n_ctiles, int nsteps, bool odd_ok = false) {
 #ifdef YOLO_CONV_TRACE
     static const int force = getenv("YOLO_TP") ? atoi(getenv("YOLO_TP")) : 0;  // measurement builds: pin the tile
-    if (force == 64 || force == 96 || force == 128 || force == 192) return force;
+    if (force == 64 || force == 96 || force == 128 || force == 192 || (force == 176 && odd_ok)) return force;
 #endif
     auto cost = [&](int tp, long long per_pixel, long long slots) {
         const long long tiles = (long long)((M + tp - 1) / tp) * n_ctiles;
@@ -890,8 +1030,20 @@ static int pick_tp(int M, int n_ctiles, int nsteps) {
         best = 192;
         c = cost(192, 92, 512);
     }
+#ifndef YOLO_NO_TP176
+    if (odd_ok && cost(176, YOLO_TP176_COST, 512) < c) {
+        best = 176;
+        c = cost(176, YOLO_TP176_COST, 512);
+    }
+#endif
     if (nsteps <= 8 && cost(64, 150, 768) < c) best = 64;
     return best;
+}
+
+// Launches the 176-pixel tile can serve, as far as the layer's shape says (the caller adds what only it knows: output
+// type, image size against the epilogue's step).
+static bool odd_tile_ok(int dtype, int Cin, int Cout, int k, bool upsample, bool stats) {
+    return dtype == YOLO_BF16 && Cin % 64 == 0 && Cout % 128 == 0 && !upsample && !stats && (k == 1 || k == 3);
 }
 
 static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
@@ -913,17 +1065,20 @@ static int conv_nsteps(int Cin, int k, int dtype) {
     return k * k * (Cin / (ROWB / (int)elem_size(dtype)));
 }
 
-// channel x pixel tile of a convolution with M output pixels
-static void conv_tile(int M, int Cin, int Cout, int k, int dtype, int* tc, int* tp) {
+// channel x pixel tile of a convolution with M output pixels (`odd_ok`: the launch may use the 176-pixel tile)
+static void conv_tile(int M, int Cin, int Cout, int k, int dtype, int* tc, int* tp, bool odd_ok = false) {
     *tc = conv_tc(Cout);
-    *tp = *tc == 128 ? pick_tp(M, (Cout + *tc - 1) / *tc, conv_nsteps(Cin, k, dtype)) : 128;
+    *tp = *tc == 128 ? pick_tp(M, (Cout + *tc - 1) / *tc, conv_nsteps(Cin, k, dtype), odd_ok) : 128;
 }
 
 template <typename T, bool TAP2>
-static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream) {
+static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream, bool odd_ok = false) {
     p.n_ctiles = (p.Cout + tc - 1) / tc;
-    const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles, p.nsteps) : 128;
+    const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles, p.nsteps, odd_ok) : 128;
     p.n_ptiles = (p.M + tp - 1) / tp;
+    if constexpr (!TAP2 && sizeof(T) == 2) {
+        if (tp == 176) return launch_conv<T, 128, 176, 2, 2, false, 4, false, false, false, true>(p, stream);
+    }
     if constexpr (!TAP2) {
         if (p.stats) {
             switch (tc) {
@@ -1065,7 +1220,10 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
         p.n_ptiles = (p.M + STRIP_TP - 1) / STRIP_TP;
         return launch_conv<bf16_t, 128, STRIP_TP, 2, 2, false, 4, false, false, true>(p, st);
     }
-    if (dtype == YOLO_BF16) return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st);
+    // the 176-pixel tile's epilogue writes bf16 and walks the output in steps of 16 pixels with one row carry
+    const bool odd_ok = odd_tile_ok(dtype, Cin, Cout, k, upsample2x != 0, stats != nullptr) && !p.y_f32 && 16 / Wo + 1 <= Ho;
+    if (dtype == YOLO_BF16)
+        return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st, odd_ok);
     return dispatch_tc<float, false>(p, tc, st);
 }
 
@@ -1305,7 +1463,9 @@ extern "C" int yolo_conv_kernel_name(const yolo_view* x, const yolo_view* y, int
         return YOLO_OK;
     }
     int tc, tp;
-    conv_tile(N * Ho * Wo, Cin, Cout, k, dtype, &tc, &tp);
+    // (a launch with f32 output, which this query is not told about, keeps the 192-pixel tile where this says 176)
+    conv_tile(N * Ho * Wo, Cin, Cout, k, dtype, &tc, &tp,
+              odd_tile_ok(dtype, Cin, Cout, k, upsample2x != 0, false) && 16 / Wo + 1 <= Ho);
     const bool tap2 = dtype == YOLO_BF16 && Cin == 32 && k == 3;
     snprintf(out, (size_t)out_len, "conv_igemm_kernel<%s,%d,%d,%s,%s>", dt, tc, tp, tc == 32 ? "1,4" : "2,2",
              tap2 ? "tap2" : "plain");
