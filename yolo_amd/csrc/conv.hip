@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     static_assert(!(STRIP && (TAP2 || S2D || STATS || sizeof(T) != 2)), "STRIP is a plain bf16 3x3 convolution");
     static_assert(WC * WP == NW, "waves");
     static_assert(!ODD || (sizeof(T) == 2 && TC == 128 && WC == 2 && WP == 2 && NW == 4 && (TP / 16) % 2 == 1 && TP % 16 == 0 &&
-                           !TAP2 && !STATS && !S2D && !STRIP),
+                           !TAP2 && !STATS && !S2D),
                   "ODD is a plain bf16 convolution on 2 x 2 waves with an odd number of pixel fragment columns");
     constexpr bool BF = sizeof(T) == 2;
     constexpr int NF = TP / 16;  // pixel fragment columns of the tile
@@ -354,26 +354,34 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
     [[maybe_unused]] auto compute_strip = [&](const char* wbuf, const char* xbuf, auto kw_c) {
         constexpr int KW = decltype(kw_c)::value;
         const int kb0 = (q ^ ((l15 + KW) & 7)) << 4;
-        const char* xb = xbuf + (wp * (TP / WP) + l15 + KW) * ROWB;
+        const char* xb = xbuf + ((ODD ? wp * 16 : wp * (TP / WP)) + l15 + KW) * ROWB;
+        [[maybe_unused]] const char* xsh = xbuf + ((NF - 1) * 16 + l15 + KW) * ROWB;  // ODD: the shared column
         bf16x8 a[2][FC], b[2][FP];
+        [[maybe_unused]] bf16x8 bsh[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int ko = kk ? ko1 : ko0;
             const int kb = kk ? (kb0 ^ 64) : kb0;
 #pragma unroll
-            for (int i = 0; i < FC; ++i) a[kk][i] = *(const bf16x8*)(wbuf + a_base + i * 16 * ROWB + ko);
+            for (int i = 0; i < FC; ++i) a[kk][i] = *(const bf16x8*)(wbuf + a_off(i) + ko);
 #pragma unroll
-            for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(xb + j * 16 * ROWB + kb);
+            for (int j = 0; j < FP; ++j) b[kk][j] = *(const bf16x8*)(xb + j * BSTEP * ROWB + kb);
+            if constexpr (ODD) bsh[kk] = *(const bf16x8*)(xsh + kb);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
                 for (int j = 0; j < FP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            if constexpr (ODD) {
+                acc_sh[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][0], bsh[kk], acc_sh[0], 0, 0, 0);
+                acc_sh[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][1], bsh[kk], acc_sh[1], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     auto compute = [&](const char* buf) {
@@ -595,13 +603,23 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             return;
         }
     }
-    // ---- ODD, with residual: f32 staging in two uneven halves, fragment columns [0, C0) and [C0, NF) -- each holds
-    //      columns of both pixel-waves (interleaved assignment), the second also the shared column; staged row s of
-    //      half h is tile pixel h * C0 * 16 + s.  Straight-line passes as in the generic path's `fast` form.
+    // ---- ODD, with residual (and every STRIP launch): f32 staging in two uneven halves, fragment columns [0, C0) and
+    //      [C0, NF) -- each holds columns of both pixel-waves (interleaved assignment), the second also the shared
+    //      column; staged row s of half h is tile pixel h * C0 * 16 + s.  Straight-line passes as in the generic path's
+    //      `fast` form.  STRIP: pixels are positions of the halo'd rows; the two halo columns of a row store nothing.
     if constexpr (ODD) {
         constexpr int J0 = (FP + 1) / 2, C0 = 2 * J0;  // own columns j < J0 of both waves = tile columns [0, C0)
-        auto run_half = [&](auto half_c) {
+        auto real_col = [&](int wo) {
+            if constexpr (STRIP) {
+                const int c = wo - 1;
+                return c < 0 ? 0 : (c >= p.Wreal ? p.Wreal - 1 : c);
+            } else {
+                return wo;
+            }
+        };
+        auto run_half = [&](auto half_c, auto res_c) {
             constexpr int HALF = decltype(half_c)::value;
+            constexpr bool RES = decltype(res_c)::value;
             constexpr int COLS = HALF == 0 ? C0 : NF - C0;
             constexpr int NPH = COLS * 16 / PPP;
             static_assert(COLS * 16 % PPP == 0 && COLS * 16 * TC * 4 <= 2 * BUF, "ODD epilogue half");
@@ -620,17 +638,19 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                     ++n;
                 }
             };
-            u32x4 rres[NPH];
-            if (ch_first < p.Cout) {
-                int n = n0, ho = ho0, wo = wo0;
-                const long long ro_first = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
-                                           wo * p.r_pix_stride + (long long)ch_first * 2;
+            [[maybe_unused]] u32x4 rres[NPH];
+            if constexpr (RES) {
+                if (ch_first < p.Cout) {
+                    int n = n0, ho = ho0, wo = wo0;
+                    const long long ro_first = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                               real_col(wo) * p.r_pix_stride + (long long)ch_first * 2;
 #pragma unroll
-                for (int pass = 0; pass < NPH; ++pass) {
-                    const long long ro = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
-                                         wo * p.r_pix_stride + (long long)ch_first * 2;
-                    rres[pass] = *(const u32x4*)(p.res + (m0 + pass * PPP < pix_end ? ro : ro_first));
-                    if (pass + 1 < NPH) step(n, ho, wo);
+                    for (int pass = 0; pass < NPH; ++pass) {
+                        const long long ro = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                             real_col(wo) * p.r_pix_stride + (long long)ch_first * 2;
+                        rres[pass] = *(const u32x4*)(p.res + (m0 + pass * PPP < pix_end ? ro : ro_first));
+                        if (pass + 1 < NPH) step(n, ho, wo);
+                    }
                 }
             }
             __syncthreads();
@@ -661,15 +681,17 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
             int n = n0, ho = ho0, wo = wo0;
 #pragma unroll
             for (int pass = 0; pass < NPH; ++pass) {
-                const bool lv = m0 + pass * PPP < pix_end && ch_first < p.Cout;
+                const bool lv = m0 + pass * PPP < pix_end && ch_first < p.Cout && (!STRIP || (wo >= 1 && wo <= p.Wreal));
                 f32x4 v0 = sv0[pass], v1 = sv1[pass];
-                const u32x4 r = rres[pass];
+                if constexpr (RES) {
+                    const u32x4 r = rres[pass];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    v0[2 * e] += __uint_as_float(r[e] << 16);
-                    v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
-                    v1[2 * e] += __uint_as_float(r[2 + e] << 16);
-                    v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
+                    for (int e = 0; e < 2; ++e) {
+                        v0[2 * e] += __uint_as_float(r[e] << 16);
+                        v0[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                        v1[2 * e] += __uint_as_float(r[2 + e] << 16);
+                        v1[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
+                    }
                 }
                 u32x4 packed;
                 packed[0] = pack_bf16x2(v0[0], v0[1]);
@@ -677,14 +699,19 @@ __global__ void __launch_bounds__(NW * 64, TP > 128 ? 2 : 1) conv_igemm_kernel(c
                 packed[2] = pack_bf16x2(v1[0], v1[1]);
                 packed[3] = pack_bf16x2(v1[2], v1[3]);
                 char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)ho * p.y_row_stride +
-                           wo * p.y_pix_stride + (size_t)ch_first * 2;
+                           real_col(wo) * p.y_pix_stride + (size_t)ch_first * 2;
                 if (lv) *(u32x4*)yp = packed;
                 if (pass + 1 < NPH) step(n, ho, wo);
             }
             TRACE_MARK(6 + 2 * HALF);
         };
-        run_half(std::integral_constant<int, 0>{});
-        run_half(std::integral_constant<int, 1>{});
+        if (p.res) {
+            run_half(std::integral_constant<int, 0>{}, std::true_type{});
+            run_half(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            run_half(std::integral_constant<int, 0>{}, std::false_type{});
+            run_half(std::integral_constant<int, 1>{}, std::false_type{});
+        }
 #ifdef YOLO_CONV_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TRACE_MARK(3);
@@ -950,8 +977,11 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, int copies = 1) 
     // two operand buffers, or the f32 epilogue staging tile if that is larger (STRIP: two weight buffers + two strips
     // of ceil((TP + 2) / 8) KiB, and the staging tile whole)
     constexpr int OPS = STRIP ? 2 * TC * ROWB + 2 * ((TP + 2 + 7) / 8) * 1024 : 2 * (TC + TP) * ROWB;
-    constexpr int STG = STRIP ? TP * TC * 4 : (TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4);
+    // staging: the f32 tile whole where it fits (STRIP: always), else bf16 whole / f32 in halves (ODD: the larger
+    // half, (TP / 32 + 1) * 16 pixels)
+    constexpr int STG = ODD ? (TP / 32 + 1) * 16 * TC * 4 : (STRIP ? TP * TC * 4 : (TP * TC * 4 > OPS ? TP * TC * 2 : TP * TC * 4));
     constexpr int LDS0 = OPS > STG ? OPS : STG;
+    static_assert(TP <= 128 || LDS0 <= 80 * 1024, "the wide tiles are built for two workgroups per CU");
 #ifdef YOLO_CONV_TRACE
     static const int LDS = getenv("YOLO_CONV_LONE") ? 100 * 1024 : LDS0;  // one workgroup per CU (measurement)
 #else
@@ -1055,6 +1085,10 @@ static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 #define YOLO_STRIP_MIN_W 40
 #endif
 constexpr int STRIP_TP = 160;
+// ... or 176 positions (11 fragment columns, the last shared by the two pixel-waves: the ODD form) where the launch
+// writes bf16: 64 x 52 x 54 positions are 1022 such tiles per channel tile (x 2: four rounds of the 512 resident
+// workgroups) instead of 1124 (4.4 rounds)
+constexpr int STRIP_TP_ODD = 176;
 static bool use_strip(int dtype, int Cin, int Cout, int k, int stride, int x_halo, int W, bool upsample, bool stats) {
     return dtype == YOLO_BF16 && k == 3 && stride == 1 && Cin % 64 == 0 && Cout > 64 && x_halo == 1 && !upsample && !stats &&
            W >= YOLO_STRIP_MIN_W;
@@ -1217,6 +1251,12 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
         p.inv_Wo = 1.0f / (float)Wv;
         p.fast_div = p.M < (1 << 24);
         p.n_ctiles = (Cout + 127) / 128;
+#ifndef YOLO_NO_STRIP176
+        if (!p.y_f32 && Cout % 128 == 0) {  // the 176-position strip tile (bf16 output: its epilogue packs)
+            p.n_ptiles = (p.M + STRIP_TP_ODD - 1) / STRIP_TP_ODD;
+            return launch_conv<bf16_t, 128, STRIP_TP_ODD, 2, 2, false, 4, false, false, true, true>(p, st);
+        }
+#endif
         p.n_ptiles = (p.M + STRIP_TP - 1) / STRIP_TP;
         return launch_conv<bf16_t, 128, STRIP_TP, 2, 2, false, 4, false, false, true>(p, st);
     }
@@ -1459,7 +1499,12 @@ extern "C" int yolo_conv_kernel_name(const yolo_view* x, const yolo_view* y, int
     const int Ho = y->H / up, Wo = y->W / up;
     const char* dt = dtype == YOLO_BF16 ? "bf16" : "float";
     if (use_strip(dtype, Cin, Cout, k, stride, x->halo, x->W, upsample2x != 0, false)) {
-        snprintf(out, (size_t)out_len, "conv_igemm_kernel<%s,128,%d,2,2,strip>", dt, STRIP_TP);
+#ifndef YOLO_NO_STRIP176
+        const int stp = Cout % 128 == 0 ? STRIP_TP_ODD : STRIP_TP;  // (bf16 output assumed, as for the plain 176 tile)
+#else
+        const int stp = STRIP_TP;
+#endif
+        snprintf(out, (size_t)out_len, "conv_igemm_kernel<%s,128,%d,2,2,strip>", dt, stp);
         return YOLO_OK;
     }
     int tc, tp;
