@@ -446,6 +446,57 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         }
     };
 
+    // ODD: the residual values of the epilogue's first half are requested under the LAST k-step's multiplications (the
+    // loops below are peeled for it: a branch inside the loop body costs the loop its schedule), so that their
+    // latency -- a read that mostly hits the Infinity Cache, ~1 us under load -- is not waited for at the first
+    // staging barrier.  One lane = 8 channels of one pixel per pass, as in the epilogue's store passes.
+#ifdef YOLO_NO_RES_PREFETCH
+    constexpr bool RES_PREFETCH = false;   // (measurement builds: the residual is requested in the epilogue)
+#else
+    constexpr bool RES_PREFETCH = ODD;
+#endif
+    constexpr int ODD_J0 = (FP + 1) / 2, ODD_C0 = 2 * ODD_J0;   // tile columns [0, C0) form the first half
+    constexpr int ODD_NP0 = ODD ? ODD_C0 * 16 / (NW * 64 / (TC / 8)) : 1;
+    [[maybe_unused]] u32x4 rres0[ODD_NP0];
+    [[maybe_unused]] auto prefetch_residual = [&]() {
+        if constexpr (ODD) {
+            constexpr int G_ = TC / 8, PPP_ = NW * 64 / G_;
+            const int ch_first_ = tile_c * TC + (tid % G_) * 8;
+            const int m0 = pix_base + tid / G_;
+            const int adv_r = PPP_ / p.Wo, adv_c = PPP_ - adv_r * p.Wo;
+            int n, ho, wo;
+            split_pixel(p, m0 < pix_end ? m0 : pix_end - 1, HoWo, n, ho, wo);
+            auto col = [&](int w_) {
+                if constexpr (STRIP) {
+                    const int c = w_ - 1;
+                    return c < 0 ? 0 : (c >= p.Wreal ? p.Wreal - 1 : c);
+                } else {
+                    return w_;
+                }
+            };
+            if (ch_first_ < p.Cout) {
+                const long long ro_first = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                           col(wo) * p.r_pix_stride + (long long)ch_first_ * 2;
+#pragma unroll
+                for (int pass = 0; pass < ODD_NP0; ++pass) {
+                    const long long ro = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
+                                         col(wo) * p.r_pix_stride + (long long)ch_first_ * 2;
+                    rres0[pass] = *(const u32x4*)(p.res + (m0 + pass * PPP_ < pix_end ? ro : ro_first));
+                    wo += adv_c;
+                    ho += adv_r;
+                    if (wo >= p.Wo) {
+                        wo -= p.Wo;
+                        ++ho;
+                    }
+                    if (ho >= p.Ho) {
+                        ho -= p.Ho;
+                        ++n;
+                    }
+                }
+            }
+        }
+    };
+
     // ---- main loop: loads of step s+1 fly while step s is multiplied
     int nsteps = S2D ? (1 + par_a) * (1 + par_b) * p.cpt : p.nsteps;
     if (p.split_steps) {
@@ -462,13 +513,13 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         int kh = 0, cc = 0;        // current group
         stage_x(xb0, 0, 0, std::integral_constant<int, -1>{});
         stage_w(wb0, 0, 0, 0);
-        for (int g = 0; g < ngroups; ++g) {
+        [[maybe_unused]] auto group = [&](int g, auto more_c) {
+            constexpr bool more = decltype(more_c)::value;
             int nkh = kh, ncc = cc + 1;  // next group
             if (ncc == p.cpt) {
                 ncc = 0;
                 ++nkh;
             }
-            const bool more = g + 1 < ngroups;
             const char* xcur = xb0 + (g & 1) * XS_BYTES;
             char* xnext = xb0 + ((g + 1) & 1) * XS_BYTES;
             // the three steps of a group alternate the weight buffers starting from (3 * g) & 1 = g & 1
@@ -481,25 +532,90 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
             if (g == 0) TRACE_MARK(1);
 #endif
             stage_w(wB, kh, 1, cc);
-            if (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 0>{});
+            if constexpr (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 0>{});
             compute_strip(wA, xcur, std::integral_constant<int, 0>{});
             // kw = 1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             stage_w(wA, kh, 2, cc);
-            if (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 1>{});
+            if constexpr (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 1>{});
             compute_strip(wB, xcur, std::integral_constant<int, 1>{});
             // kw = 2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (more) {
+            if constexpr (more) {
                 stage_w(wB, nkh, 0, ncc);
                 stage_x(xnext, nkh, ncc, std::integral_constant<int, 2>{});
+            } else if constexpr (RES_PREFETCH) {
+                if (p.res) prefetch_residual();
             }
             compute_strip(wA, xcur, std::integral_constant<int, 2>{});
             kh = nkh;
             cc = ncc;
+        };
+        if constexpr (ODD) {  // last group peeled: no branch in the loop body
+            for (int g = 0; g + 1 < ngroups; ++g) group(g, std::true_type{});
+            group(ngroups - 1, std::false_type{});
+        } else {
+            for (int g = 0; g < ngroups; ++g) {
+                int nkh = kh, ncc = cc + 1;  // next group
+                if (ncc == p.cpt) {
+                    ncc = 0;
+                    ++nkh;
+                }
+                const bool more = g + 1 < ngroups;
+                const char* xcur = xb0 + (g & 1) * XS_BYTES;
+                char* xnext = xb0 + ((g + 1) & 1) * XS_BYTES;
+                char* const wA = wb0 + (g & 1) * W_BYTES;
+                char* const wB = wb0 + ((g + 1) & 1) * W_BYTES;
+                // kw = 0
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+#ifdef YOLO_CONV_TRACE
+                if (g == 0) TRACE_MARK(1);
+#endif
+                stage_w(wB, kh, 1, cc);
+                if (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 0>{});
+                compute_strip(wA, xcur, std::integral_constant<int, 0>{});
+                // kw = 1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                stage_w(wA, kh, 2, cc);
+                if (more) stage_x(xnext, nkh, ncc, std::integral_constant<int, 1>{});
+                compute_strip(wB, xcur, std::integral_constant<int, 1>{});
+                // kw = 2
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (more) {
+                    stage_w(wB, nkh, 0, ncc);
+                    stage_x(xnext, nkh, ncc, std::integral_constant<int, 2>{});
+                }
+                compute_strip(wA, xcur, std::integral_constant<int, 2>{});
+                kh = nkh;
+                cc = ncc;
+            }
         }
+    } else if constexpr (ODD) {  // last k-step peeled: the first residual values are requested under it
+        stage(smem);
+        int s = 0;
+        for (; s + 1 < nsteps; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#ifdef YOLO_CONV_TRACE
+            if (s == 0) TRACE_MARK(1);
+#endif
+            stage(smem + ((s + 1) & 1) * BUF);
+            compute(smem + (s & 1) * BUF);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#ifdef YOLO_CONV_TRACE
+        if (s == 0) TRACE_MARK(1);
+#endif
+        if constexpr (RES_PREFETCH) {
+            if (p.res) prefetch_residual();
+        }
+        compute(smem + (s & 1) * BUF);
     } else {
     stage(smem);
     for (int s = 0; s < nsteps; ++s) {
@@ -650,8 +766,12 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                     ++n;
                 }
             };
+            static_assert(HALF != 0 || NPH == ODD_NP0, "the first half's residual is requested before the loop ends");
             [[maybe_unused]] u32x4 rres[NPH];
-            if constexpr (RES) {
+            if constexpr (RES && HALF == 0 && RES_PREFETCH) {
+#pragma unroll
+                for (int pass = 0; pass < NPH; ++pass) rres[pass] = rres0[pass];
+            } else if constexpr (RES) {
                 if (ch_first < p.Cout) {
                     int n = n0, ho = ho0, wo = wo0;
                     const long long ro_first = p.r_origin + (long long)n * p.r_img_stride + (long long)ho * p.r_row_stride +
@@ -1043,12 +1163,13 @@ static int launch_conv_copies(const ConvParams& p, int copies, hipStream_t strea
 // set-up three times as often (measured ~1.5 x the cost per pixel), but fills the chip on layers with few pixels;
 // it is only considered for 1x1 layers with K <= 512, where nothing else does.
 //
-// The 176-pixel tile (11 fragment columns, the last shared by the two pixel-waves: see the kernel) costs 9 % more LDS
-// reads per multiply than the 192-pixel tile; it exists for the layers whose tile count it brings under a whole number
-// of rounds (64 images of 13 x 13 or 26 x 26 pixels: 496 / 984 tiles instead of 456 / 904 larger ones).  Only offered
+// The 176-pixel tile (11 fragment columns, the last shared by the two pixel-waves: see the kernel) issues 9 % more LDS
+// reads per multiply than the 192-pixel tile, but measures the same time per pixel (tools/tp_sweep.sh: the loop is not
+// bound by LDS reads); it exists for the layers whose tile count it brings under a whole number of rounds (64 images of
+// 13 x 13 or 26 x 26 pixels: 496 / 984 tiles instead of 456 / 904 larger ones), and wins narrowly elsewhere.  Only offered
 // (`odd_ok`) to launches its epilogue handles: bf16 in and out, no upsample, no BatchNorm sums, no split-K.
 #ifndef YOLO_TP176_COST
-#define YOLO_TP176_COST 96
+#define YOLO_TP176_COST 92
 #endif
 static int pick_tp(int M, int n_ctiles, int nsteps, bool odd_ok = false) {
 #ifdef YOLO_CONV_TRACE
