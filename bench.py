@@ -519,9 +519,37 @@ def run_rank(args) -> None:
             # ranks the collective backend really connected (RCCL when the backend is nccl)
             out["n_ranks_" + ("rccl" if dist.get_backend() == "nccl" else dist.get_backend())] = dist.get_world_size()
     # the secondary (training) measurement is collective when world > 1: every rank runs it (the others wait in its
-    # first collective while rank 0 finishes the records above), rank 0 reports it
+    # first collective while rank 0 finishes the records above), rank 0 reports it.  A collective that never completes
+    # cannot be interrupted from Python, so at world > 1 a watchdog thread bounds the block: when it fires, rank 0 prints
+    # the line it has (with the reason in place of the training record) and every rank leaves the process.
     if not args.no_train and hasattr(w, "train"):
-        train_rec = w.train()
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if out is not None:
+                    out["train"] = {"error": f"training block did not finish within {args.train_timeout:.0f} s "
+                                             f"(world {world}): abandoned by the watchdog"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)   # the headline line is out (rank 0); the reason travels in it
+
+            watchdog = threading.Timer(args.train_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            train_rec = w.train()
+        except Exception as e:
+            if world == 1:
+                raise
+            # a rank that left the collective leaves its peers waiting: they end through their own watchdogs
+            train_rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if out is not None:
+                out["train"] = train_rec
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        if watchdog is not None:
+            watchdog.cancel()
         if out is not None:
             out["train"] = train_rec
     if out is not None:
@@ -540,6 +568,8 @@ def main(argv=None) -> int:
                     help="repeat the K steps until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput measurement")
+    ap.add_argument("--train-timeout", type=float, default=240.0,
+                    help="world > 1: seconds after which the (collective) training block is abandoned")
     argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

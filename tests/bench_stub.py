@@ -51,3 +51,16 @@ class StubWorkload:
 
 def make(rank, world, local):
     return StubWorkload(rank, world, local)
+
+
+class HangingTrainStub(StubWorkload):
+    """Rank 1 never reaches the training block's collective: rank 0 waits in it for ever."""
+
+    def train(self):
+        if self.rank == 1:
+            time.sleep(3600)
+        return super().train()
+
+
+def make_hanging(rank, world, local):
+    return HangingTrainStub(rank, world, local)

@@ -59,3 +59,18 @@ def test_a_failing_rank_fails_the_launch(monkeypatch, capfd):
     monkeypatch.setenv("PYTHONPATH", os.pathsep.join([bench.ROOT] + sys.path))
     assert bench.main(["--gpus", "2", "--steps", "1", "--warmup", "0"]) != 0
     capfd.readouterr()
+
+
+def test_a_training_block_that_hangs_does_not_take_the_headline_line_with_it(capfd, monkeypatch):
+    """At world > 1 the training block is a collective; if it never completes (a rank stuck, a transport problem), the
+    watchdog prints the line measured so far with the reason in place of the training record, and the job ends."""
+    monkeypatch.setenv("YOLO_BENCH_WORKLOAD", "tests.bench_stub:make_hanging")
+    monkeypatch.setenv("YOLO_BENCH_BACKEND", "gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([bench.ROOT] + sys.path))
+    rc = bench.main(["--gpus", "2", "--steps", "1", "--warmup", "0", "--min-seconds", "0", "--train-timeout", "3"])
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "watchdog" in rec["train"]["error"]
