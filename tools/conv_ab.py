@@ -8,11 +8,13 @@ import torch
 sys.path.insert(0, ".")
 from yolo_amd import _lib, ops  # noqa: E402
 
-# (Cin, Cout, k, stride, H, residual): the 3x3 / stride-1 layers of Darknet-53 + neck at 416 x 416 and a few others
+# (Cin, Cout, k, stride, H, residual): the 3x3 / stride-1 layers of Darknet-53 + neck at 416 x 416 and a few others;
+# Cout 255 = the head convolutions (f32 output, linear)
 LAYERS = [(64, 128, 3, 1, 104, 1), (128, 256, 3, 1, 52, 1), (128, 256, 3, 1, 52, 0), (256, 512, 3, 1, 26, 1),
           (256, 512, 3, 1, 26, 0), (512, 1024, 3, 1, 13, 1), (512, 1024, 3, 1, 13, 0),
           (256, 128, 1, 1, 52, 0), (512, 256, 1, 1, 26, 0), (256, 512, 3, 2, 52, 0), (1024, 512, 1, 1, 13, 0),
-          (128, 64, 1, 1, 104, 0), (512, 1024, 3, 2, 26, 0)]
+          (128, 64, 1, 1, 104, 0), (512, 1024, 3, 2, 26, 0), (256, 255, 1, 1, 52, 0), (512, 255, 1, 1, 26, 0),
+          (1024, 255, 1, 1, 13, 0), (64, 128, 3, 2, 208, 0), (128, 256, 3, 2, 104, 0), (384, 128, 1, 1, 52, 0)]
 
 
 def main():
@@ -27,11 +29,13 @@ def main():
         w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
         wp, bp = ops.pack_conv(w, torch.zeros(cout), torch.bfloat16, dev)
         Ho = (H + 2 * (k // 2) - k) // s + 1
-        y = ops.alloc_view(N, Ho, Ho, cout, 1, torch.bfloat16, dev)
+        head = cout == 255
+        y = ops.alloc_view(N, Ho, Ho, (cout + 7) // 8 * 8, 0 if head else 1, torch.float32 if head else torch.bfloat16, dev)
         r = ops.alloc_view(N, Ho, Ho, cout, 1, torch.bfloat16, dev) if res else None
         if r is not None:
             r.interior().copy_(torch.randn(N, Ho, Ho, cout, generator=g).to(dev))
-        run = lambda: ops.conv2d_fwd(x, wp, bp, y, cin=cin, cout=cout, k=k, stride=s, residual=r)
+        run = lambda: ops.conv2d_fwd(x, wp, bp, y, cin=cin, cout=cout, k=k, stride=s, residual=r,
+                                     slope=1.0 if head else 0.1)
         times = {0: [], 1: []}
         names = {}
         for rnd in range(7):

@@ -32,6 +32,10 @@ class PlanCache:
     def keys(self):
         return list(self._plans.keys())
 
+    def values(self):
+        """The cached plans, least recently used first."""
+        return [plan for plan, _ in self._plans.values()]
+
     @property
     def nbytes(self) -> int:
         return sum(b for _, b in self._plans.values())
