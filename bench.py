@@ -120,12 +120,27 @@ class Yolov3Inference:
         self.last = None
         torch.cuda.synchronize()
 
-    def run(self, k: int):
+    def run(self, k: int, lanes: int = 1):
         """k complete steps in the engine's throughput mode; every step's NMS + gather is enqueued before this
-        returns."""
+        returns.  The headline runs ONE lane (one batch's convolutions on the GPU at a time), so that the per-kernel
+        durations behind ``roofline`` are those of kernels that have the chip to themselves."""
         for out in self.eng.detect_pipelined((self.imgs for _ in range(k)), score_thr=self.thr, nms_thr=self.nms_thr,
-                                             mean=self.mean, std=self.std, max_det=100):
+                                             mean=self.mean, std=self.std, max_det=100, lanes=lanes):
             self.last = out
+
+    def two_lanes(self, k: int = 100) -> dict:
+        """The same steps with consecutive batches alternating between two main streams (Yolov3Engine.detect_pipelined,
+        ``lanes=2``): what this GPU delivers when two batches share it.  Secondary: not the headline."""
+        torch = self.torch
+        self.eng.plan(BATCH, SIZE, SIZE, 2)
+        self.run(6, lanes=2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.run(k, lanes=2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(BATCH * k / dt, 1), "unit": "images/sec on this GPU", "steps": k,
+                "ms_per_step": round(dt / k * 1e3, 3)}
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -513,6 +528,8 @@ def run_rank(args) -> None:
         }
         if hasattr(w, "postproc"):
             out["postproc"] = w.postproc()
+        if hasattr(w, "two_lanes"):
+            out["two_lane_throughput"] = w.two_lanes()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = w.cpu_baseline()
         if dist is not None:

@@ -169,9 +169,10 @@ def test_every_layer_bf16_teacher_forced(cuda, calibrated):
     assert worst < 2e-2  # one bf16 ulp at the top of the range is 2^-8; typical worst layer is ~4e-3
 
 
-def test_pipelined_detect_equals_detect(cuda, calibrated):
-    """Throughput mode (submit batch i+1 before finishing batch i, two buffer sets) returns exactly what the
-    synchronous detect() returns for each batch, in order."""
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_pipelined_detect_equals_detect(cuda, calibrated, lanes):
+    """Throughput mode (submit batch i+1 before finishing batch i, two buffer sets; with two lanes: consecutive
+    batches on two main streams) returns exactly what the synchronous detect() returns for each batch, in order."""
     model, cfg, sd = calibrated
     model.backbone.compute_dtype = torch.bfloat16
     eng = model.backbone.engine()
@@ -185,7 +186,7 @@ def test_pipelined_detect_equals_detect(cuda, calibrated):
                 break
         want.append((det.clone(), n.clone()))
     eng._plans.clear()   # the throughput mode starts from the default candidate capacity and has to cope on its own
-    got = [(d.clone(), n.clone()) for d, n in eng.detect_pipelined(iter(batches), **kw)]
+    got = [(d.clone(), n.clone()) for d, n in eng.detect_pipelined(iter(batches), lanes=lanes, **kw)]
     assert len(got) == len(want)
     total = 0
     for (d0, n0), (d1, n1) in zip(want, got):
