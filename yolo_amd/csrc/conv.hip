@@ -232,6 +232,30 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         const int row = 8 * (wave + NW * i) + lrow;
         wsrc[i] = p.w + (size_t)(tile_c * TC + row) * p.w_row_bytes + schunk * 16;
     }
+    // The first k-step's weight rows are requested now, ahead of the pixel-address arithmetic below (a pixel ->
+    // (image, row, column) split and carried steps per tile row): their flight time covers it.
+#ifndef YOLO_NO_EARLY_W
+    constexpr bool EARLY_W = !S2D;
+#else
+    constexpr bool EARLY_W = false;
+#endif
+    if constexpr (EARLY_W) {
+        const int woff0 = (p.split_steps ? split * p.split_steps : 0) * ROWB;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff0, smem + (wave + NW * i) * 1024);
+    }
+    // ... and the first k-step's pixel rows are requested row by row as their addresses come out of that arithmetic.
+#ifndef YOLO_NO_EARLY_X
+    constexpr bool EARLY_X = EARLY_W && !TAP2;
+#else
+    constexpr bool EARLY_X = false;
+#endif
+    int xoff0 = 0;
+    if (EARLY_X && p.split_steps) {  // first k-step of this split -> (tap, channel chunk)
+        const int s0 = split * p.split_steps;
+        const int tap = s0 / p.cpt, cc0 = s0 - tap * p.cpt, kh0 = tap / p.ksize, kw0 = tap - kh0 * p.ksize;
+        xoff0 = kh0 * p.x_row_stride + kw0 * p.x_pix_stride + cc0 * ROWB;
+    }
     const int HoWo = p.Ho * p.Wo;
     {
         // this lane's pixel rows are 8 * NW pixels apart: one pixel -> (image, row, column) split, then carried steps
@@ -254,6 +278,13 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                 if (STRIP && mfirst < 0) --wo;  // position -1 read position 0 (its output is a halo column); step on from -1
             }
             xsrc[i] = mfirst + STEP * i < pix_end ? a : first;  // tail rows read a valid pixel; never stored
+            if constexpr (EARLY_X) {
+                if constexpr (STRIP) {
+                    if (wave + NW * i < SP) glds16(xsrc[i] + xoff0, smem + 2 * W_BYTES + (wave + NW * i) * 1024);
+                } else {
+                    if (XEVEN || wave + NW * i < XPIECES) glds16(xsrc[i] + xoff0, smem + W_BYTES + (wave + NW * i) * 1024);
+                }
+            }
             if (i + 1 < NX) {
                 if (xtiny) {
                     const int m = mfirst + STEP * (i + 1);
@@ -284,7 +315,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         cur_kh = tap / p.ksize;
         cur_kw = tap - cur_kh * p.ksize;
     }
-    auto stage = [&](char* buf) {
+    auto stage = [&](char* buf, bool skip_w = false, bool skip_x = false) {
         int xoff;
         if constexpr (TAP2) {
             const int t0 = 2 * cur_step;
@@ -301,11 +332,15 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
             const int kh = par_a ? 2 * cur_kh : 1, kw = par_b ? 2 * cur_kw : 1;
             woff = ((kh * 3 + kw) * p.cpt + cur_cc) * ROWB;
         }
+        if (!skip_w) {
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + NW * i) * 1024);
+            for (int i = 0; i < NWP; ++i) glds16(wsrc[i] + woff, buf + (wave + NW * i) * 1024);
+        }
+        if (!skip_x) {
 #pragma unroll
-        for (int i = 0; i < NXP; ++i)
-            if (XEVEN || wave + NW * i < XPIECES) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + NW * i) * 1024);
+            for (int i = 0; i < NXP; ++i)
+                if (XEVEN || wave + NW * i < XPIECES) glds16(xsrc[i] + xoff, buf + W_BYTES + (wave + NW * i) * 1024);
+        }
         ++cur_step;
         if (++cur_cc == p.cpt) {
             cur_cc = 0;
@@ -511,8 +546,8 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         char* const xb0 = smem + 2 * W_BYTES;
         const int ngroups = 3 * p.cpt;
         int kh = 0, cc = 0;        // current group
-        stage_x(xb0, 0, 0, std::integral_constant<int, -1>{});
-        stage_w(wb0, 0, 0, 0);
+        if constexpr (!EARLY_X) stage_x(xb0, 0, 0, std::integral_constant<int, -1>{});
+        if constexpr (!EARLY_W) stage_w(wb0, 0, 0, 0);
         [[maybe_unused]] auto group = [&](int g, auto more_c) {
             constexpr bool more = decltype(more_c)::value;
             int nkh = kh, ncc = cc + 1;  // next group
@@ -596,7 +631,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
             }
         }
     } else if constexpr (ODD) {  // last k-step peeled: the first residual values are requested under it
-        stage(smem);
+        stage(smem, EARLY_W, EARLY_X);
         int s = 0;
         for (; s + 1 < nsteps; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -617,7 +652,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         }
         compute(smem + (s & 1) * BUF);
     } else {
-    stage(smem);
+    stage(smem, EARLY_W, EARLY_X);
     for (int s = 0; s < nsteps; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
