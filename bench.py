@@ -528,7 +528,7 @@ def run_rank(args) -> None:
         }
         if hasattr(w, "postproc"):
             out["postproc"] = w.postproc()
-        if hasattr(w, "two_lanes"):
+        if hasattr(w, "two_lanes") and not args.no_two_lanes:
             out["two_lane_throughput"] = w.two_lanes()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = w.cpu_baseline()
@@ -585,6 +585,8 @@ def main(argv=None) -> int:
                     help="repeat the K steps until the timed region is at least this long (0: exactly K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput measurement")
+    ap.add_argument("--no-two-lanes", action="store_true",
+                    help="skip the secondary two-lane throughput pass (profiling runs: its kernels overlap each other)")
     ap.add_argument("--train-timeout", type=float, default=240.0,
                     help="world > 1: seconds after which the (collective) training block is abandoned")
     argv = sys.argv[1:] if argv is None else list(argv)

@@ -34,12 +34,13 @@ def per_kernel(path, counter):
 def short(name):
     """The name yolo_conv_kernel_name() gives the instance (what bench.py looks up), from the profiler's mangled or
     demangled kernel name; template arguments: element type, tile channels, tile pixels, wave layout (2), two taps per
-    k-step, waves, BatchNorm sums, stride-2 data gradient, strip form."""
+    k-step, waves, BatchNorm sums, stride-2 data gradient, strip form (and, not part of the name, the shared-column
+    form of tiles with an odd number of pixel fragment columns: it is implied by 176)."""
     m = re.search(r"conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d)ELi(\d)ELb(\d)ELi\d+ELb(\d)ELb(\d)ELb(\d)", name)
     if m:
         g = list(m.groups())
     else:
-        m = re.search(r"conv_igemm_kernel<([^,]+), *(\d+), *(\d+), *(\d), *(\d), *(\w+), *\d+, *(\w+), *(\w+), *(\w+)>", name)
+        m = re.search(r"conv_igemm_kernel<([^,]+), *(\d+), *(\d+), *(\d), *(\d), *(\w+), *\d+, *(\w+), *(\w+), *(\w+)(?:, *\w+)?>", name)
         if not m:
             return re.sub(r"^void |\(.*$", "", name).replace("yolo::", "")[:44]
         g = list(m.groups())
