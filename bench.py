@@ -327,15 +327,37 @@ def _postproc_in_step(w: "Yolov3Inference", steps: int = 6) -> dict:
     touched_dec = rows * 64 + min(n_cand, rows) * K * es + n_cand * 28
     alg_nms = n_cand * 24 + 8 * n_det + 2 * n_cand * 8
     out = {}
-    for label, alg, touched in (("decode", alg_dec, touched_dec), ("nms_gather", alg_nms, alg_nms)):
-        ts = acc.get(label)
+
+    def record(label, key, alg, touched, events, where):
+        ts = events.get(label)
         if not ts:
-            continue
+            return
         t = statistics.median(ts)
-        out[label] = dict(in_step_us=round(t, 1), algorithmic_bytes=int(alg), touched_bytes_lower_bound=int(touched),
-                          algorithmic_gbytes_per_s=round(alg / t / 1e3, 1),
-                          frac_hbm_algorithmic=round(alg / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
-                          frac_hbm_touched=round(touched / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+        out[key] = dict(in_step_us=round(t, 1), stream=where, algorithmic_bytes=int(alg),
+                        touched_bytes_lower_bound=int(touched), algorithmic_gbytes_per_s=round(alg / t / 1e3, 1),
+                        frac_hbm_algorithmic=round(alg / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                        frac_hbm_touched=round(touched / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+
+    side = "its own stream, next to the following batch's convolutions (the default: hidden, but it shares the chip)"
+    record("decode", "decode", alg_dec, touched_dec, acc, side if eng.decode_on_side_stream else "main stream")
+    record("nms_gather", "nms_gather", alg_nms, alg_nms, acc, side if eng.nms_on_side_stream else "main stream")
+    # the same steps with the decode launches on the main stream, directly behind the last head convolution and with
+    # nothing else on the chip: what the three decode kernels do when they have the GPU (costs 0.7 % images/s: they are
+    # then no longer hidden behind the next batch)
+    if eng.decode_on_side_stream:
+        eng.decode_on_side_stream = False
+        try:
+            eng.trace_events = []
+            w.run(steps)
+            torch.cuda.synchronize()
+            ev2, eng.trace_events = eng.trace_events, None
+        finally:
+            eng.decode_on_side_stream = True
+        acc2 = {}
+        for label, a, b in ev2:
+            acc2.setdefault(label, []).append(a.elapsed_time(b) * 1e3)
+        record("decode", "decode_on_main_stream", alg_dec, touched_dec, acc2,
+               "main stream, behind the last head convolution, alone on the chip")
     return out
 
 

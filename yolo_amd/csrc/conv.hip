@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         // share a CU: they get neighbouring tiles (same pixel tile, next channel tile), so that the pixel operand the
         // second one asks for is still in the CU's vector cache.  Placement is not guaranteed: speed only (measured
         // 2 % on the 26 x 26 and 13 x 13 3x3 layers; mixed on the strip form, which keeps the plain order).
-        if constexpr (!STRIP) {
+        if (!STRIP && !p.y_f32) {  // (the f32 head outputs, bound by their stores, measured 1-3 % slower paired)
             const int run = xcd < r ? q + 1 : q;              // tiles of this XCD
             const int grp = j >> 6, in = j & 63;
             if ((grp + 1) * 64 <= run) j = grp * 64 + ((in & 31) << 1) + (in >> 5);
