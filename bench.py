@@ -148,6 +148,14 @@ class Yolov3Inference:
     def reduce_device(self):
         return self.device
 
+    def device_label(self) -> str:
+        """Which physical GPU this rank ran on (ordinal, PCI address, name): two ranks on one card show up as equal
+        labels in the line's per_rank_device."""
+        i = self.device.index
+        pr = self.torch.cuda.get_device_properties(i)
+        pci = "%04x:%02x:%02x" % tuple(getattr(pr, k, 0) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        return f"cuda:{i} {pci} {pr.name}"
+
     # ---- reporting (rank 0) ----
     def config(self, world: int, steps_total: int, elapsed: float) -> dict:
         plan = self.eng.plan(BATCH, SIZE, SIZE)
@@ -526,6 +534,12 @@ def run_rank(args) -> None:
         dist.all_reduce(mine, op=dist.ReduceOp.MAX)
         elapsed = float(mine.item())
 
+    label = w.device_label() if hasattr(w, "device_label") else f"rank {rank}"
+    labels = [label]
+    if dist is not None:
+        labels = [None] * world
+        dist.all_gather_object(labels, label)
+
     total_steps = repeats * args.steps
     out = None
     if rank == 0:
@@ -545,6 +559,8 @@ def run_rank(args) -> None:
             "timed_steps": total_steps,
             "timed_seconds": round(elapsed, 3),
             "per_rank_value": [round(w.units_per_step * total_steps / t, 1) for t in per_rank],
+            "per_rank_device": labels,
+            "ranks_on_distinct_devices": len(set(labels)) == world,
             "config": w.config(world, total_steps, elapsed),
             "roofline": w.roofline(),
         }

@@ -27,6 +27,9 @@ class StubWorkload:
     def reduce_device(self):
         return "cpu"
 
+    def device_label(self):
+        return f"stub device {self.rank}"
+
     def config(self, world, steps_total, elapsed):
         return {"workload": "stub", "steps_run_on_rank0": self.steps_run}
 
@@ -64,3 +67,14 @@ class HangingTrainStub(StubWorkload):
 
 def make_hanging(rank, world, local):
     return HangingTrainStub(rank, world, local)
+
+
+class SameDeviceStub(StubWorkload):
+    """Every rank reports the same device, as ranks that mis-bound their GPU would."""
+
+    def device_label(self):
+        return "stub device 0"
+
+
+def make_same_device(rank, world, local):
+    return SameDeviceStub(rank, world, local)

@@ -35,6 +35,8 @@ def test_gpus_2_starts_two_ranks(capfd, monkeypatch):
     # the training block is measured at N > 1 too, by all ranks together (its all-reduce saw both of them)
     assert rec["train"]["n_gpus"] == 2 and rec["train"]["params_in_sync"] and rec["train"]["exchange"] == "allreduce"
     assert rec["n_ranks_gloo"] == 2
+    # every rank names the device it ran on
+    assert rec["per_rank_device"] == ["stub device 0", "stub device 1"] and rec["ranks_on_distinct_devices"]
 
 
 def test_gpus_1_is_one_process(capfd, monkeypatch):
@@ -74,3 +76,16 @@ def test_a_training_block_that_hangs_does_not_take_the_headline_line_with_it(cap
     assert rc == 0 and len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and "watchdog" in rec["train"]["error"]
+
+
+def test_ranks_sharing_a_device_show_in_the_line(capfd, monkeypatch):
+    monkeypatch.setenv("YOLO_BENCH_WORKLOAD", "tests.bench_stub:make_same_device")
+    monkeypatch.setenv("YOLO_BENCH_BACKEND", "gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([bench.ROOT] + sys.path))
+    rc = bench.main(["--gpus", "2", "--steps", "1", "--warmup", "0", "--min-seconds", "0", "--no-train"])
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["per_rank_device"] == ["stub device 0"] * 2 and rec["ranks_on_distinct_devices"] is False
