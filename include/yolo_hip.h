@@ -261,15 +261,17 @@ size_t yolo_bn_workspace_bytes(int N, int H, int W, int C);
 /*
  * The same convolution as yolo_conv2d_fwd (linear, no residual, output type = operand type) that also leaves
  * the first pass of the following training-mode BatchNorm (detectron2 Conv2d.forward: F.conv2d, then self.norm):
- *   sums  [rows][2][Cout] f32, rows = yolo_conv2d_bnsums_rows(N*Ho*Wo, Cin, Cout, k, dtype): per pixel tile and channel, the sum
- *         of the output values as stored and of their squares
+ *   sums  [rows][2][Cout] f32, rows = yolo_conv2d_bnsums_rows(x, y, N, Cin, Cout, k, stride, dtype): per pixel tile
+ *         (of the form and tile the launch picks for these views) and channel, the sum of the output values as stored
+ *         and of their squares
  * yolo_bn_train_finalize turns the rows into what yolo_bn_train_stats writes (stats [5][C], running statistics);
  * count = N*Ho*Wo.  Together they replace yolo_conv2d_fwd + yolo_bn_train_stats without re-reading z.
  */
 int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* y,
                            int N, int Cin, int Cout, int k, int stride, int dtype, float* sums,
                            size_t sums_bytes, void* stream);
-int yolo_conv2d_bnsums_rows(int M, int Cin, int Cout, int k, int dtype);
+int yolo_conv2d_bnsums_rows(const yolo_view* x, const yolo_view* y, int N, int Cin, int Cout, int k, int stride,
+                            int dtype);
 int yolo_bn_train_finalize(const float* sums, int rows, long long count, int C, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, float* stats, void* stream);
@@ -286,6 +288,27 @@ int yolo_bn_act_fwd(const yolo_view* z, const float* stats, const yolo_view* res
 int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const float* stats, const yolo_view* dz,
                     int N, int C, float leaky_slope, int dtype, float* dgamma, float* dbeta,
                     void* workspace, size_t ws_bytes, void* stream);
+
+/*
+ * The data-gradient convolution of a layer (yolo_conv2d_fwd with the transposed, tap-rotated weights, linear, optional
+ * residual = the gradient's other contributions, stride 1, bf16) when its output y IS the gradient dL/da of an
+ * activation a = leaky(bn(z)) produced by a training-mode BatchNorm (darknet.py:116,120,123; fpn.py:35,69,98): the
+ * epilogue also leaves the reduction pass of that BatchNorm's backward,
+ *   sums  [rows][2][Cout] f32, rows = yolo_conv2d_bnsums_rows(x, y, ..., stride 1, ...): per pixel tile and channel,
+ *         sum g and sum g*z with
+ *         g = y * leaky'(z*bn_scale + bn_shift), y as stored
+ *   z, bn_scale, bn_shift, act_slope   the producer's saved pre-normalisation output and rows 3 and 4 of its stats
+ * yolo_bn_act_bwd_presummed then finishes what yolo_bn_act_bwd does (dgamma, dbeta, dz) in two launches instead of
+ * three, reading dy and z once instead of twice.  What autograd runs as separate kernels in the reference
+ * (losses.backward(), tools/train_net.py -> DefaultTrainer.run_step).
+ */
+int yolo_conv2d_fwd_bnbwd_sums(const yolo_view* x, const void* w_packed, const float* bias,
+                               const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
+                               int dtype, const yolo_view* z, const float* bn_scale, const float* bn_shift,
+                               float act_slope, float* sums, size_t sums_bytes, void* stream);
+int yolo_bn_act_bwd_presummed(const yolo_view* dy, const yolo_view* z, const float* stats, const yolo_view* dz,
+                              int N, int C, float leaky_slope, int dtype, float* dgamma, float* dbeta,
+                              const float* sums, int rows, void* stream);
 
 /*
  * Weight gradient of F.conv2d (bf16 or f32 operands per `dtype`, f32 result):

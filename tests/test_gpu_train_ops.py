@@ -221,7 +221,8 @@ def test_pack_conv_train_batch(cuda, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(3, 64, 128, 3, 1, 20, 12), (2, 128, 64, 1, 1, 13, 13), (2, 64, 256, 3, 2, 16, 16),
-                                   (5, 128, 256, 1, 1, 9, 7)], ids=lambda s: "x".join(map(str, s)))
+                                   (5, 128, 256, 1, 1, 9, 7), (87, 64, 128, 3, 1, 32, 32), (2, 64, 128, 3, 1, 52, 52),
+                                   (4, 128, 256, 1, 1, 106, 106)], ids=lambda s: "x".join(map(str, s)))
 def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
     """yolo_conv2d_fwd_bnsums + yolo_bn_train_finalize against yolo_conv2d_fwd + yolo_bn_train_stats: the same z
     bit for bit, the same statistics (sums of the stored z, folded in fp64 in both) and running-stat update."""
@@ -240,7 +241,7 @@ def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
         stats = torch.zeros(5, cout, device=cuda)
         rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
         if fused:
-            sums = torch.full((ops.conv_bnsums_rows(N * Ho * Wo, cin, cout, k, dtype) * 2 * cout,), float("nan"), device=cuda)
+            sums = torch.full((ops.conv_bnsums_rows(x, z, cin, cout, k, s) * 2 * cout,), float("nan"), device=cuda)
             rows = ops.conv2d_fwd_bnsums(x, wp, bp, z, sums, cin=cin, cout=cout, k=k, stride=s)
             ops.bn_train_finalize(sums, rows, N * Ho * Wo, gamma, beta, stats, eps=1e-5, momentum=0.1,
                                   running_mean=rm, running_var=rv)
@@ -253,6 +254,63 @@ def test_conv_with_bn_sums_equals_conv_then_stats(cuda, shape, dtype):
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1:], res[1][1:]):
         assert torch.isfinite(b).all() and _rel(b, a) < 2e-5
+
+
+# (N, Cin, Cout, k, H, W, form): form = what the launch is expected to pick, read off the number of rows of sums --
+# "176": the 176-pixel tile, "strip": the 176-position strip form (rows of W + 2 positions), None: whatever fits
+@pytest.mark.parametrize("shape", [(3, 128, 64, 3, 20, 12, None), (2, 64, 128, 1, 13, 13, None), (4, 256, 128, 3, 26, 26, None),
+                                   (2, 128, 256, 1, 52, 52, None), (1, 64, 64, 3, 5, 3, None), (2, 256, 512, 3, 13, 13, None),
+                                   (87, 64, 128, 3, 32, 32, "176"), (4, 128, 256, 1, 106, 106, "176"),
+                                   (2, 64, 128, 3, 52, 52, "strip"), (5, 128, 256, 3, 41, 45, "strip")],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("with_residual", [False, True], ids=["plain", "accumulate"])
+def test_dgrad_with_bn_backward_sums_equals_dgrad_then_bn_backward(cuda, shape, with_residual):
+    """yolo_conv2d_fwd_bnbwd_sums + yolo_bn_act_bwd_presummed against yolo_conv2d_fwd + yolo_bn_act_bwd: the same dy bit
+    for bit (the sums do not change what the convolution stores), the same dz to bf16 rounding and the same dgamma /
+    dbeta (both reduce g and g * zhat over the stored dy and z; the orders of summation differ)."""
+    from yolo_amd import ops
+    N, cin, cout, k, H, W, form = shape   # the data-gradient convolution: cin -> cout; the BatchNorm has cout channels
+    torch.manual_seed(31)
+    dt = torch.bfloat16
+    x = ops.alloc_view(N, H, W, cin, 1, dt, cuda)
+    x.interior().normal_()
+    w = torch.randn(cout, cin, k, k) * (2.0 / (cin * k * k)) ** 0.5
+    wp, bp = ops.pack_conv(w, torch.zeros(cout), dt, cuda)
+    z = ops.alloc_view(N, H, W, cout, 0, dt, cuda)
+    z.interior().normal_(0.3, 1.5)
+    res = None
+    if with_residual:
+        res = ops.alloc_view(N, H, W, cout, 1, dt, cuda)
+        res.interior().normal_()
+    gamma, beta = torch.rand(cout, device=cuda) + 0.5, torch.randn(cout, device=cuda) * 0.5
+    stats = torch.zeros(5, cout, device=cuda)
+    ws = torch.empty(ops.bn_workspace_bytes(N, H, W, cout), dtype=torch.uint8, device=cuda)
+    ops.bn_train_stats(z, gamma, beta, stats, ws, eps=1e-5, momentum=0.1)
+    out = []
+    for fused in (False, True):
+        dy = ops.alloc_view(N, H, W, cout, 1, dt, cuda)
+        dz = ops.alloc_view(N, H, W, cout, 1, dt, cuda)
+        dgamma, dbeta = torch.zeros(cout, device=cuda), torch.zeros(cout, device=cuda)
+        if fused:
+            sums = torch.full((ops.conv_bnsums_rows(x, dy, cin, cout, k) * 2 * cout,), float("nan"), device=cuda)
+            rows = ops.conv2d_fwd_bnbwd_sums(x, wp, bp, dy, sums, cin=cin, cout=cout, k=k, z=z, stats=stats,
+                                             act_slope=0.1, residual=res)
+            if form == "176":
+                assert rows == -(-N * H * W // 176)
+            elif form == "strip":
+                assert rows == -(-N * H * (W + 2) // 176)
+            ops.bn_act_bwd_presummed(dy, z, stats, dz, dgamma, dbeta, sums, rows, slope=0.1)
+        else:
+            ops.conv2d_fwd(x, wp, bp, dy, cin=cin, cout=cout, k=k, stride=1, slope=1.0, residual=res)
+            ops.bn_act_bwd(dy, z, stats, dz, dgamma, dbeta, ws, slope=0.1)
+        torch.cuda.synchronize()
+        out.append((dy.buf.clone(), dz.buf.float().clone(), dgamma, dbeta))
+    # the convolution may run another tile shape with the sums (the result of a tile does not depend on its shape)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.isfinite(out[1][2]).all() and torch.isfinite(out[1][3]).all()
+    assert _rel(out[1][3], out[0][3]) < 1e-4 and _rel(out[1][2], out[0][2]) < 1e-4
+    assert float((out[1][1] - out[0][1]).abs().max()) <= 2 ** -7 * float(out[0][1].abs().max())
+    assert float((out[1][1] != out[0][1]).float().mean()) < 0.02
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 256, 13, 13), (3, 256, 512, 7, 9), (1, 128, 128, 26, 20), (2, 512, 1024, 5, 5)],

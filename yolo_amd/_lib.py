@@ -90,7 +90,11 @@ SIGNATURES = {
                                     c_void_p]),
     "yolo_conv2d_fwd_bnsums": (c_int, [_VP, c_void_p, c_void_p, _VP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_size_t, c_void_p]),
-    "yolo_conv2d_bnsums_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "yolo_conv2d_bnsums_rows": (c_int, [_VP, _VP, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "yolo_conv2d_fwd_bnbwd_sums": (c_int, [_VP, c_void_p, c_void_p, _VP, _VP, c_int, c_int, c_int, c_int, c_int, _VP,
+                                           c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "yolo_bn_act_bwd_presummed": (c_int, [_VP, _VP, c_void_p, _VP, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_int, c_void_p]),
     "yolo_bn_train_finalize": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_float, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "yolo_aug_letterbox": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_int, c_int, ctypes.c_longlong,

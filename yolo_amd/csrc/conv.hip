@@ -53,6 +53,15 @@ struct ConvParams {
     int split_steps;            // split-K launches: k-steps per split (0 = the whole k range in one workgroup)
     long long y_split_stride;   // split-K launches: bytes between the f32 partial-sum slabs of consecutive splits
     float* stats;  // STATS kernels: per pixel tile, per channel: [n_ptiles][2][Cout] sums of y and y*y
+    // STATS kernels, BatchNorm-backward form (bz != null): y is the gradient dL/da of an activation a = leaky(bn(z)) and
+    // the sums are (sum g, sum g * z) with g = y * leaky'(z * bz_scale + bz_shift): the reduction pass of that
+    // BatchNorm's backward, taken from the epilogue that writes the gradient.
+    const char* bz;
+    long long bz_img_stride, bz_origin;  // bytes
+    int bz_row_stride, bz_pix_stride;
+    const float* bz_scale;  // [Cout]: gamma * invstd
+    const float* bz_shift;  // [Cout]: beta - mean * gamma * invstd
+    float bz_slope;
 };
 
 constexpr int ROWB = 128;  // bytes of k per tile row and per k-step
@@ -117,7 +126,8 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // T: element type of x / w / residual.  TC x TP: channel x pixel tile of one workgroup (4 waves laid
 // out WC x WP).  TAP2: bf16 with Cin == 32, one k-step spans two filter taps.
 // STATS: additionally leave, per pixel tile, the per-channel sums of the output values as stored (after rounding
-// to the output type) and of their squares -- the first pass of a training-mode BatchNorm over this output.
+// to the output type) and of their squares -- the first pass of a training-mode BatchNorm over this output; or (p.bz
+// set, bf16) the two sums of the BatchNorm-backward reduction of the layer whose output gradient the launch writes.
 //
 // S2D: data gradient of a 3x3 / stride-2 / pad-1 convolution without materialising the zero-dilated gradient.
 // x is dz [Hi x Wi], y is dx [2Hi x 2Wi]; output pixel (2i+a, 2j+b) only meets the taps kh' with a+kh'-1 even
@@ -145,12 +155,14 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // indices in both waves, wave wp keeps channel fragment f in slot f ^ 2wp: slots 0 and 1 are always the shared ones.
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
           bool STRIP = false, bool ODD = false>
-__global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(const ConvParams p) {
+// (the instances with sums keep the occupancy their LDS request allows: the second form of the sums needs registers the
+// compiler otherwise takes without regard to it)
+__global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : (STATS ? (TP >= 96 ? 2 : 3) : 1)) conv_igemm_kernel(const ConvParams p) {
     static_assert(!(S2D && (TAP2 || STATS)), "S2D is a plain bf16/f32 convolution");
-    static_assert(!(STRIP && (TAP2 || S2D || STATS || sizeof(T) != 2)), "STRIP is a plain bf16 3x3 convolution");
+    static_assert(!(STRIP && (TAP2 || S2D || (STATS && !ODD) || sizeof(T) != 2)), "STRIP is a plain bf16 3x3 convolution");
     static_assert(WC * WP == NW, "waves");
     static_assert(!ODD || (sizeof(T) == 2 && TC == 128 && WC == 2 && WP == 2 && NW == 4 && (TP / 16) % 2 == 1 && TP % 16 == 0 &&
-                           !TAP2 && !STATS && !S2D),
+                           !TAP2 && !S2D),
                   "ODD is a plain bf16 convolution on 2 x 2 waves with an odd number of pixel fragment columns");
     constexpr bool BF = sizeof(T) == 2;
     constexpr int NF = TP / 16;  // pixel fragment columns of the tile
@@ -682,6 +694,73 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
     }
+    // BatchNorm-backward sums: g = dy * leaky'(z * scale + shift) per element; st_s += g, st_q += g * z (the
+    // normalisation of z is applied to the sums afterwards, once per channel)
+    [[maybe_unused]] float bsc[STATS ? 8 : 1], bsh[STATS ? 8 : 1];
+    if constexpr (STATS) {
+        if (p.bz && ch_first < p.Cout) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bsc[e] = p.bz_scale[ch_first + e];
+                bsh[e] = p.bz_shift[ch_first + e];
+            }
+        }
+    }
+    [[maybe_unused]] auto bz_accumulate = [&](const u32x4 dy, const u32x4 zz) {
+        if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = __uint_as_float(dy[e] << 16), d1 = __uint_as_float(dy[e] & 0xffff0000u);
+                const float z0 = __uint_as_float(zz[e] << 16), z1 = __uint_as_float(zz[e] & 0xffff0000u);
+                const float g0 = z0 * bsc[2 * e] + bsh[2 * e] >= 0.f ? d0 : d0 * p.bz_slope;
+                const float g1 = z1 * bsc[2 * e + 1] + bsh[2 * e + 1] >= 0.f ? d1 : d1 * p.bz_slope;
+                st_s[2 * e] += g0;
+                st_q[2 * e] += g0 * z0;
+                st_s[2 * e + 1] += g1;
+                st_q[2 * e + 1] += g1 * z1;
+            }
+        }
+    };
+    [[maybe_unused]] auto bz_offset = [&](int n, int ho, int wo) {  // wo: a real pixel column
+        return p.bz_origin + (long long)n * p.bz_img_stride + (long long)ho * p.bz_row_stride + wo * p.bz_pix_stride +
+               (long long)ch_first * 2;
+    };
+    // sums of the stored values and of their squares (the forward form)
+    [[maybe_unused]] auto sq_accumulate = [&](const u32x4 packed) {
+        if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z0 = __uint_as_float(packed[e] << 16);
+                const float z1 = __uint_as_float(packed[e] & 0xffff0000u);
+                st_s[2 * e] += z0;
+                st_q[2 * e] += z0 * z0;
+                st_s[2 * e + 1] += z1;
+                st_q[2 * e + 1] += z1 * z1;
+            }
+        }
+    };
+    // fold the pixel lanes of the workgroup: [which][pixel lane][channel] through LDS (the staged tile is done)
+    [[maybe_unused]] auto finish_stats = [&]() {
+        if constexpr (STATS) {
+            constexpr int PL = NW * 64 / G;
+            float* red = (float*)smem;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(tid / G) * TC + g * 8 + e] = st_s[e];
+                red[(PL + tid / G) * TC + g * 8 + e] = st_q[e];
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * TC; t += NW * 64) {
+                const int which = t / TC, c = t - which * TC;
+                float a = 0.f;
+#pragma unroll 4
+                for (int l = 0; l < PL; ++l) a += red[(which * PL + l) * TC + c];
+                const int cg = tile_c * TC + c;
+                if (cg < p.Cout) p.stats[((long long)tile_p * 2 + which) * p.Cout + cg] = a;
+            }
+        }
+    };
     // A tile staged in two halves: every wave stages half of its own pixel columns in each half (all waves write,
     // none waits), so a half holds two runs of HP/2 tile pixels, HP/2 apart: staged row s is tile pixel
     // half * HP/2 + s (+ HP/2 from the second run on).  JUMP = that extra distance, met once per lane and half.
@@ -693,10 +772,35 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
     // ---- bf16 output without residual (two launches of three): the tile is rounded in registers and staged as bf16
     //      -- half the LDS bytes, and a 128 x 192 tile (48 KB) goes through in ONE piece instead of two halves: one
     //      barrier pair less.  Same values as the f32-staged path (LeakyReLU in f32, one rounding).
-    if constexpr (BF && TC == 128 && !STATS && !TAP2 && !STRIP) {
+    if constexpr (BF && TC == 128 && (!STATS || ODD) && !TAP2 && !STRIP) {
         // (the ODD instance is only launched for bf16 output without upsample or split-K on images of at least a step)
         if (!p.res && (ODD || (!p.y_f32 && !p.upsample && !p.split_steps && adv_rows + 1 <= p.Ho))) {
             constexpr int NPB = TP / PPP;
+            [[maybe_unused]] u32x4 rz[STATS ? NPB : 1];   // BatchNorm-backward sums: this lane's z values, requested
+            if constexpr (STATS) {                          // before the tile is staged
+                if (p.bz && ch_first < p.Cout) {
+                    const int mz = pix_base + prow;
+                    int n, ho, wo;
+                    split_pixel(p, mz < pix_end ? mz : pix_end - 1, HoWo, n, ho, wo);
+                    const long long zo_first = bz_offset(n, ho, wo);
+#pragma unroll
+                    for (int pass = 0; pass < NPB; ++pass) {
+                        rz[pass] = *(const u32x4*)(p.bz + (mz + pass * PPP < pix_end ? bz_offset(n, ho, wo) : zo_first));
+                        if (pass + 1 < NPB) {
+                            wo += adv_cols;
+                            ho += adv_rows;
+                            if (wo >= p.Wo) {
+                                wo -= p.Wo;
+                                ++ho;
+                            }
+                            if (ho >= p.Ho) {
+                                ho -= p.Ho;
+                                ++n;
+                            }
+                        }
+                    }
+                }
+            }
             __syncthreads();  // every wave is done with the operand buffers
             {
                 const int ch0 = wc * (TC / WC) + q * 4;
@@ -745,6 +849,14 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                 char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)oh * p.y_row_stride +
                            ow * p.y_pix_stride + (size_t)ch_first * 2;
                 if (lv) *(u32x4*)yp = sv[pass];
+                if constexpr (STATS) {
+                    if (lv) {
+                        if (p.bz)
+                            bz_accumulate(sv[pass], rz[pass]);
+                        else
+                            sq_accumulate(sv[pass]);
+                    }
+                }
                 if (pass + 1 < NPB) {
                     wo += adv_cols;
                     ho += adv_rows;
@@ -763,6 +875,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TRACE_MARK(3);
 #endif
+            finish_stats();
             return;
         }
     }
@@ -802,6 +915,18 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                 }
             };
             static_assert(HALF != 0 || NPH == ODD_NP0, "the first half's residual is requested before the loop ends");
+            [[maybe_unused]] u32x4 rz[STATS ? NPH : 1];
+            if constexpr (STATS) {
+                if (p.bz && ch_first < p.Cout) {
+                    int n = n0, ho = ho0, wo = wo0;
+                    const long long zo_first = bz_offset(n, ho, real_col(wo));
+#pragma unroll
+                    for (int pass = 0; pass < NPH; ++pass) {
+                        rz[pass] = *(const u32x4*)(p.bz + (m0 + pass * PPP < pix_end ? bz_offset(n, ho, real_col(wo)) : zo_first));
+                        if (pass + 1 < NPH) step(n, ho, wo);
+                    }
+                }
+            }
             [[maybe_unused]] u32x4 rres[NPH];
             if constexpr (RES && HALF == 0 && RES_PREFETCH) {
 #pragma unroll
@@ -868,6 +993,14 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                 char* yp = ybase + p.y_origin + (long long)n * p.y_img_stride + (long long)ho * p.y_row_stride +
                            real_col(wo) * p.y_pix_stride + (size_t)ch_first * 2;
                 if (lv) *(u32x4*)yp = packed;
+                if constexpr (STATS) {
+                    if (lv) {
+                        if (p.bz)
+                            bz_accumulate(packed, rz[pass]);
+                        else
+                            sq_accumulate(packed);
+                    }
+                }
                 if (pass + 1 < NPH) step(n, ho, wo);
             }
             TRACE_MARK(6 + 2 * HALF);
@@ -883,6 +1016,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TRACE_MARK(3);
 #endif
+        finish_stats();
         return;
     }
 #pragma unroll
@@ -935,6 +1069,23 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                (long long)ch_first * (int)sizeof(T);
     };
     [[maybe_unused]] u32x4 rres[NP];
+    [[maybe_unused]] u32x4 rbz[STATS ? NP : 1];   // BatchNorm-backward sums: this lane's z values of the half
+    if constexpr (STATS && BF) {
+        if (p.bz && ch_first < p.Cout) {   // requested with the residual, before the tile is staged
+            int n = n0, ho = ho0, wo = wo0;
+            const long long zo_first = bz_offset(n, ho, wo);
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                rbz[pass] = *(const u32x4*)(p.bz + (pixel_of_pass(pass) < pix_end ? bz_offset(n, ho, wo) : zo_first));
+                if (pass + 1 < NP) {
+                    if (fast)
+                        advance(std::true_type{}, pass, n, ho, wo);
+                    else
+                        advance(std::false_type{}, pass, n, ho, wo);
+                }
+            }
+        }
+    }
     auto load_residual = [&](auto fast_c) {
         int n = n0, ho = ho0, wo = wo0;
         const long long ro_first = res_offset(n, ho, wo);
@@ -1027,14 +1178,10 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                     }
                     if constexpr (STATS && !YF) {
                         if (lv) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float z0 = __uint_as_float(packed[e] << 16);
-                                const float z1 = __uint_as_float(packed[e] & 0xffff0000u);
-                                st_s[2 * e] += z0;
-                                st_q[2 * e] += z0 * z0;
-                                st_s[2 * e + 1] += z1;
-                                st_q[2 * e + 1] += z1 * z1;
+                            if (p.bz) {
+                                bz_accumulate(packed, rbz[pass]);
+                            } else {
+                                sq_accumulate(packed);
                             }
                         }
                     }
@@ -1074,7 +1221,11 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                                 *(u32x4*)o = packed;
                             }
                         }
-                    if constexpr (STATS) {
+                    if constexpr (STATS && BF) {
+                        if (p.bz && !p.y_f32) bz_accumulate(packed, rbz[pass]);
+                    }
+                    if (!(STATS && BF) || !p.bz) {
+                      if constexpr (STATS) {
                         float z[8];
                         if (p.y_f32) {
 #pragma unroll
@@ -1094,6 +1245,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
                             st_s[e] += z[e];
                             st_q[e] += z[e] * z[e];
                         }
+                      }
                     }
                 }
                 if (pass + 1 < NP) advance(fast_c, pass, n, ho, wo);
@@ -1116,26 +1268,7 @@ __global__ void __launch_bounds__(NW * 64, TP >= 128 ? 2 : 1) conv_igemm_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the wave's queue
     TRACE_MARK(3);
 #endif
-    if constexpr (STATS) {
-        // fold the pixel lanes of the workgroup: [which][pixel lane][channel] through LDS (the staged tile is done)
-        constexpr int PL = NW * 64 / G;
-        float* red = (float*)smem;
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[(tid / G) * TC + g * 8 + e] = st_s[e];
-            red[(PL + tid / G) * TC + g * 8 + e] = st_q[e];
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * TC; t += NW * 64) {
-            const int which = t / TC, c = t - which * TC;
-            float a = 0.f;
-#pragma unroll 4
-            for (int l = 0; l < PL; ++l) a += red[(which * PL + l) * TC + c];
-            const int cg = tile_c * TC + c;
-            if (cg < p.Cout) p.stats[((long long)tile_p * 2 + which) * p.Cout + cg] = a;
-        }
-    }
+    finish_stats();
 }
 
 template <typename T, int TC, int TP, int WC, int WP, bool TAP2, int NW = 4, bool STATS = false, bool S2D = false,
@@ -1202,7 +1335,7 @@ static int launch_conv_copies(const ConvParams& p, int copies, hipStream_t strea
 // reads per multiply than the 192-pixel tile, but measures the same time per pixel (tools/tp_sweep.sh: the loop is not
 // bound by LDS reads); it exists for the layers whose tile count it brings under a whole number of rounds (64 images of
 // 13 x 13 or 26 x 26 pixels: 496 / 984 tiles instead of 456 / 904 larger ones), and wins narrowly elsewhere.  Only offered
-// (`odd_ok`) to launches its epilogue handles: bf16 in and out, no upsample, no BatchNorm sums, no split-K.
+// (`odd_ok`) to launches its epilogue handles: bf16 in and out, no upsample, no split-K.
 #ifndef YOLO_TP176_COST
 #define YOLO_TP176_COST 92
 #endif
@@ -1240,8 +1373,8 @@ static int pick_tp(int M, int n_ctiles, int nsteps, bool odd_ok = false) {
 
 // Launches the 176-pixel tile can serve, as far as the layer's shape says (the caller adds what only it knows: output
 // type, image size against the epilogue's step).
-static bool odd_tile_ok(int dtype, int Cin, int Cout, int k, bool upsample, bool stats) {
-    return dtype == YOLO_BF16 && Cin % 64 == 0 && Cout % 128 == 0 && !upsample && !stats && (k == 1 || k == 3);
+static bool odd_tile_ok(int dtype, int Cin, int Cout, int k, bool upsample) {
+    return dtype == YOLO_BF16 && Cin % 64 == 0 && Cout % 128 == 0 && !upsample && (k == 1 || k == 3);
 }
 
 static int conv_tc(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
@@ -1257,9 +1390,10 @@ constexpr int STRIP_TP = 160;
 // writes bf16: 64 x 52 x 54 positions are 1022 such tiles per channel tile (x 2: four rounds of the 512 resident
 // workgroups) instead of 1124 (4.4 rounds)
 constexpr int STRIP_TP_ODD = 176;
+// (with BatchNorm sums only the 176-position form below has the epilogue for them)
 static bool use_strip(int dtype, int Cin, int Cout, int k, int stride, int x_halo, int W, bool upsample, bool stats) {
-    return dtype == YOLO_BF16 && k == 3 && stride == 1 && Cin % 64 == 0 && Cout > 64 && x_halo == 1 && !upsample && !stats &&
-           W >= YOLO_STRIP_MIN_W;
+    return dtype == YOLO_BF16 && k == 3 && stride == 1 && Cin % 64 == 0 && Cout > 64 && x_halo == 1 && !upsample &&
+           (!stats || Cout % 128 == 0) && W >= YOLO_STRIP_MIN_W;
 }
 
 static int conv_nsteps(int Cin, int k, int dtype) {
@@ -1273,13 +1407,24 @@ static void conv_tile(int M, int Cin, int Cout, int k, int dtype, int* tc, int* 
     *tp = *tc == 128 ? pick_tp(M, (Cout + *tc - 1) / *tc, conv_nsteps(Cin, k, dtype), odd_ok) : 128;
 }
 
+static int check_sums_bytes(const ConvParams& p, size_t stats_bytes) {
+    YOLO_REQUIRE(!p.stats || stats_bytes >= (size_t)p.n_ptiles * 2 * p.Cout * sizeof(float),
+                 "conv2d with BatchNorm sums: buffer of %zu bytes is too small (%d rows of 2 x %d)", stats_bytes, p.n_ptiles,
+                 p.Cout);
+    return YOLO_OK;
+}
+
 template <typename T, bool TAP2>
-static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream, bool odd_ok = false) {
+static int dispatch_tc(ConvParams& p, int tc, hipStream_t stream, bool odd_ok = false, size_t stats_bytes = 0) {
     p.n_ctiles = (p.Cout + tc - 1) / tc;
     const int tp = tc == 128 ? pick_tp(p.M, p.n_ctiles, p.nsteps, odd_ok) : 128;
     p.n_ptiles = (p.M + tp - 1) / tp;
+    if (int e = check_sums_bytes(p, stats_bytes)) return e;
     if constexpr (!TAP2 && sizeof(T) == 2) {
-        if (tp == 176) return launch_conv<T, 128, 176, 2, 2, false, 4, false, false, false, true>(p, stream);
+        if (tp == 176) {
+            if (p.stats) return launch_conv<T, 128, 176, 2, 2, false, 4, true, false, false, true>(p, stream);
+            return launch_conv<T, 128, 176, 2, 2, false, 4, false, false, false, true>(p, stream);
+        }
     }
     if constexpr (!TAP2) {
         if (p.stats) {
@@ -1318,9 +1463,18 @@ extern "C" int yolo_conv_tile_shape(int M, int Cin, int Cout, int k, int dtype, 
 }
 
 
+// BatchNorm-backward form of the sums (see ConvParams::bz)
+struct BnBackwardSums {
+    const yolo_view* z;
+    const float* scale;
+    const float* shift;
+    float slope;
+};
+
 static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* residual,
                        const yolo_view* y, int N, int Cin, int Cout, int k, int stride, float leaky_slope, int upsample2x,
-                       int dtype, int y_dtype, float* stats, size_t stats_bytes, void* stream) {
+                       int dtype, int y_dtype, float* stats, size_t stats_bytes, void* stream,
+                       const BnBackwardSums* bwd = nullptr) {
     YOLO_REQUIRE(x && y && w_packed && bias, "conv2d: null argument");
     YOLO_REQUIRE(dtype == YOLO_F32 || dtype == YOLO_BF16, "conv2d: dtype %d", dtype);
     YOLO_REQUIRE(y_dtype == YOLO_F32 || y_dtype == YOLO_BF16, "conv2d: y_dtype %d", y_dtype);
@@ -1400,11 +1554,25 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
 
     const int tc = conv_tc(Cout);
     if (stats) {
-        YOLO_REQUIRE(!tap2 && !upsample2x && !residual, "conv2d with BatchNorm sums: plain convolutions only");
-        const int tp = tc == 128 ? pick_tp(p.M, (Cout + tc - 1) / tc, p.nsteps) : 128;
-        YOLO_REQUIRE(stats_bytes >= (size_t)((p.M + tp - 1) / tp) * 2 * Cout * sizeof(float),
-                     "conv2d with BatchNorm sums: buffer of %zu bytes is too small", stats_bytes);
-        p.stats = stats;
+        YOLO_REQUIRE(!tap2 && !upsample2x && (!residual || bwd), "conv2d with BatchNorm sums: plain convolutions only");
+        if (bwd) {
+            YOLO_REQUIRE(dtype == YOLO_BF16 && y_dtype == YOLO_BF16 && Cout % 8 == 0,
+                         "conv2d with BatchNorm-backward sums: bf16, Cout %d a multiple of 8", Cout);
+            YOLO_REQUIRE(bwd->z && bwd->z->ptr && bwd->scale && bwd->shift && bwd->z->H == Ho && bwd->z->W == Wo &&
+                             bwd->z->ch_offset % 8 == 0 && bwd->z->ch_total % 8 == 0 &&
+                             bwd->z->ch_offset + Cout <= bwd->z->ch_total,
+                         "conv2d with BatchNorm-backward sums: z view mismatch");
+            const ViewGeom gz = geom_of(*bwd->z);
+            p.bz = (const char*)bwd->z->ptr;
+            p.bz_img_stride = gz.img_stride * 2;
+            p.bz_row_stride = gz.row_stride * 2;
+            p.bz_pix_stride = gz.pix_stride * 2;
+            p.bz_origin = (long long)gz.origin * 2;
+            p.bz_scale = bwd->scale;
+            p.bz_shift = bwd->shift;
+            p.bz_slope = bwd->slope;
+        }
+        p.stats = stats;   // (the buffer's size is checked against the tile count once the tile is chosen)
     }
     hipStream_t st = (hipStream_t)stream;
     if (use_strip(dtype, Cin, Cout, k, stride, x->halo, x->W, upsample2x != 0, stats != nullptr)) {
@@ -1422,17 +1590,20 @@ static int conv2d_impl(const yolo_view* x, const void* w_packed, const float* bi
 #ifndef YOLO_NO_STRIP176
         if (!p.y_f32 && Cout % 128 == 0) {  // the 176-position strip tile (bf16 output: its epilogue packs)
             p.n_ptiles = (p.M + STRIP_TP_ODD - 1) / STRIP_TP_ODD;
+            if (int e = check_sums_bytes(p, stats_bytes)) return e;
+            if (p.stats) return launch_conv<bf16_t, 128, STRIP_TP_ODD, 2, 2, false, 4, true, false, true, true>(p, st);
             return launch_conv<bf16_t, 128, STRIP_TP_ODD, 2, 2, false, 4, false, false, true, true>(p, st);
         }
 #endif
+        YOLO_REQUIRE(!p.stats, "conv2d with BatchNorm sums: the 160-position strip form has no epilogue for them");
         p.n_ptiles = (p.M + STRIP_TP - 1) / STRIP_TP;
         return launch_conv<bf16_t, 128, STRIP_TP, 2, 2, false, 4, false, false, true>(p, st);
     }
     // the 176-pixel tile's epilogue writes bf16 and walks the output in steps of 16 pixels with one row carry
-    const bool odd_ok = odd_tile_ok(dtype, Cin, Cout, k, upsample2x != 0, stats != nullptr) && !p.y_f32 && 16 / Wo + 1 <= Ho;
+    const bool odd_ok = odd_tile_ok(dtype, Cin, Cout, k, upsample2x != 0) && !p.y_f32 && 16 / Wo + 1 <= Ho;
     if (dtype == YOLO_BF16)
-        return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st, odd_ok);
-    return dispatch_tc<float, false>(p, tc, st);
+        return tap2 ? dispatch_tc<bf16_t, true>(p, tc, st) : dispatch_tc<bf16_t, false>(p, tc, st, odd_ok, stats_bytes);
+    return dispatch_tc<float, false>(p, tc, st, false, stats_bytes);
 }
 
 namespace yolo {
@@ -1678,7 +1849,7 @@ extern "C" int yolo_conv_kernel_name(const yolo_view* x, const yolo_view* y, int
     int tc, tp;
     // (a launch with f32 output, which this query is not told about, keeps the 192-pixel tile where this says 176)
     conv_tile(N * Ho * Wo, Cin, Cout, k, dtype, &tc, &tp,
-              odd_tile_ok(dtype, Cin, Cout, k, upsample2x != 0, false) && 16 / Wo + 1 <= Ho);
+              odd_tile_ok(dtype, Cin, Cout, k, upsample2x != 0) && 16 / Wo + 1 <= Ho);
     const bool tap2 = dtype == YOLO_BF16 && Cin == 32 && k == 3;
     snprintf(out, (size_t)out_len, "conv_igemm_kernel<%s,%d,%d,%s,%s>", dt, tc, tp, tc == 32 ? "1,4" : "2,2",
              tap2 ? "tap2" : "plain");
@@ -1692,11 +1863,16 @@ extern "C" int yolo_conv2d_fwd(const yolo_view* x, const void* w_packed, const f
                        nullptr, 0, stream);
 }
 
-extern "C" int yolo_conv2d_bnsums_rows(int M, int Cin, int Cout, int k, int dtype) {
-    if (M <= 0 || Cin <= 0 || Cout <= 0) return 0;
+// mirrors conv2d_impl's choice of form and tile for a launch with sums (bf16 / f32 in = out, no upsample)
+extern "C" int yolo_conv2d_bnsums_rows(const yolo_view* x, const yolo_view* y, int N, int Cin, int Cout, int k, int stride,
+                                       int dtype) {
+    if (!x || !y || N <= 0 || Cin <= 0 || Cout <= 0 || y->H <= 0 || y->W <= 0) return 0;
+    const int Ho = y->H, Wo = y->W;
+    if (use_strip(dtype, Cin, Cout, k, stride, x->halo, x->W, false, true))
+        return (int)(((long long)N * Ho * (Wo + 2) + STRIP_TP_ODD - 1) / STRIP_TP_ODD);
     int tc, tp;
-    conv_tile(M, Cin, Cout, k, dtype, &tc, &tp);
-    return (M + tp - 1) / tp;
+    conv_tile(N * Ho * Wo, Cin, Cout, k, dtype, &tc, &tp, odd_tile_ok(dtype, Cin, Cout, k, false) && 16 / Wo + 1 <= Ho);
+    return (N * Ho * Wo + tp - 1) / tp;
 }
 
 extern "C" int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, const float* bias, const yolo_view* y,
@@ -1705,6 +1881,18 @@ extern "C" int yolo_conv2d_fwd_bnsums(const yolo_view* x, const void* w_packed, 
     YOLO_REQUIRE(sums, "conv2d_fwd_bnsums: null argument");
     return conv2d_impl(x, w_packed, bias, nullptr, y, N, Cin, Cout, k, stride, 1.0f, 0, dtype, dtype, sums, sums_bytes,
                        stream);
+}
+
+extern "C" int yolo_conv2d_fwd_bnbwd_sums(const yolo_view* x, const void* w_packed, const float* bias,
+                                          const yolo_view* residual, const yolo_view* y, int N, int Cin, int Cout, int k,
+                                          int dtype, const yolo_view* z, const float* bn_scale, const float* bn_shift,
+                                          float act_slope, float* sums, size_t sums_bytes, void* stream) {
+    YOLO_REQUIRE(sums && z && bn_scale && bn_shift, "conv2d_fwd_bnbwd_sums: null argument");
+    YOLO_REQUIRE(act_slope >= 0.f && act_slope <= 1.f, "conv2d_fwd_bnbwd_sums: leaky slope %g outside [0, 1]",
+                 (double)act_slope);
+    const BnBackwardSums bwd{z, bn_scale, bn_shift, act_slope};
+    return conv2d_impl(x, w_packed, bias, residual, y, N, Cin, Cout, k, 1, 1.0f, 0, dtype, dtype, sums, sums_bytes,
+                       stream, &bwd);
 }
 
 extern "C" int yolo_conv3x3s2_dgrad(const yolo_view* dz, const void* w_dgrad_packed, const float* bias,

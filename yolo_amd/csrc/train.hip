@@ -252,9 +252,12 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const FinParams p) {
             p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
             p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
         }
-    } else {
+    } else if constexpr (MODE == 1) {
         p.dbeta[c] = (float)a;
         p.dgamma[c] = (float)b;
+    } else {  // the sums are (sum g, sum g * z): sum g * zhat = (sum g * z - mean * sum g) * invstd
+        p.dbeta[c] = (float)a;
+        p.dgamma[c] = (float)((b - (double)p.mean[c] * a) * (double)p.invstd[c]);
     }
 }
 
@@ -650,6 +653,47 @@ extern "C" int yolo_bn_act_bwd(const yolo_view* dy, const yolo_view* z, const fl
     p.dbeta = dbeta;
     p.slope = leaky_slope;
     p.inv_count = (float)(1.0 / (double)r.M);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<unsigned short, 1>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<float, 1>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
+    YOLO_CHECK_HIP(hipGetLastError());
+    return YOLO_OK;
+}
+
+// The same backward step when the reduction came out of the epilogue that wrote dy (yolo_conv2d_fwd_bnbwd_sums):
+// `sums` holds `rows` rows of [2][C] partial sums (sum g, sum g * z); two launches instead of three, dy and z read once.
+extern "C" int yolo_bn_act_bwd_presummed(const yolo_view* dy, const yolo_view* z, const float* stats, const yolo_view* dz,
+                                         int N, int C, float leaky_slope, int dtype, float* dgamma, float* dbeta,
+                                         const float* sums, int rows, void* stream) {
+    YOLO_REQUIRE(stats && dgamma && dbeta && sums && rows > 0, "bn_act_bwd_presummed: bad argument");
+    if (int e = check_slice(dy, C, "bn_act_bwd_presummed")) return e;
+    if (int e = check_slice(z, C, "bn_act_bwd_presummed")) return e;
+    if (int e = check_slice(dz, C, "bn_act_bwd_presummed")) return e;
+    YOLO_REQUIRE(dy->H == z->H && dy->W == z->W && dz->H == z->H && dz->W == z->W, "bn_act_bwd_presummed: sizes differ");
+    const int es = (int)elem_size(dtype);
+    const long long M = (long long)N * z->H * z->W;
+    hipStream_t st = (hipStream_t)stream;
+    FinParams f{};
+    f.partial = sums;
+    f.blocks = rows;
+    f.C = C;
+    f.count = (double)M;
+    f.mean = const_cast<float*>(stats);
+    f.invstd = const_cast<float*>(stats) + 2 * C;
+    f.dgamma = dgamma;
+    f.dbeta = dbeta;
+    hipLaunchKernelGGL((bn_finalize_kernel<2>), dim3((C + 7) / 8), dim3(1024), 0, st, f);
+    ApplyParams p{};
+    fill_apply(p, z, dy, dz, N, C, es);
+    p.mean = stats;
+    p.invstd = stats + 2 * C;
+    p.scale = stats + 3 * C;
+    p.shift = stats + 4 * C;
+    p.dgamma = dgamma;
+    p.dbeta = dbeta;
+    p.slope = leaky_slope;
+    p.inv_count = (float)(1.0 / (double)M);
     if (dtype == YOLO_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<unsigned short, 1>), dim3(apply_grid(p.total)), dim3(256), 0, st, p);
     else

@@ -175,9 +175,11 @@ def conv_kernel_name(x: "View", y: "View", cin: int, cout: int, k: int, stride: 
     return buf.value.decode()
 
 
-def conv_bnsums_rows(M: int, cin: int, cout: int, k: int, dtype: torch.dtype) -> int:
-    """Rows of per-tile sums conv2d_fwd_bnsums writes for this convolution."""
-    return lib().yolo_conv2d_bnsums_rows(int(M), int(cin), int(cout), int(k), dtype_code(dtype))
+def conv_bnsums_rows(x: "View", y: "View", cin: int, cout: int, k: int, stride: int = 1) -> int:
+    """Rows of per-tile sums conv2d_fwd_bnsums / conv2d_fwd_bnbwd_sums write for this convolution (x -> y)."""
+    xv, yv = x.c(), y.c()
+    return lib().yolo_conv2d_bnsums_rows(ctypes.byref(xv), ctypes.byref(yv), x.N, int(cin), int(cout), int(k), int(stride),
+                                         dtype_code(x.buf.dtype))
 
 
 def pack_stem(weight: torch.Tensor, bias: torch.Tensor, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -617,12 +619,47 @@ def conv2d_fwd_bnsums(x: View, w_packed: torch.Tensor, bias: torch.Tensor, z: Vi
     BatchNorm needs.  Returns the number of rows written to ``sums`` ([rows, 2, cout] f32)."""
     _require_cuda(x.buf, "conv2d_fwd_bnsums")
     assert sums.dtype == torch.float32 and sums.is_contiguous() and z.buf.dtype == x.buf.dtype
-    rows = conv_bnsums_rows(x.N * z.H * z.W, cin, cout, k, x.buf.dtype)
+    rows = conv_bnsums_rows(x, z, cin, cout, k, stride)
     xv, zv = x.c(), z.c()
     check(lib().yolo_conv2d_fwd_bnsums(ctypes.byref(xv), _ptr(w_packed), _ptr(bias), ctypes.byref(zv), x.N, cin, cout, k,
                                        stride, dtype_code(x.buf.dtype), _ptr(sums), sums.numel() * 4, _stream()),
           "yolo_conv2d_fwd_bnsums")
     return rows
+
+
+def conv2d_fwd_bnbwd_sums(x: View, w_packed: torch.Tensor, bias: torch.Tensor, y: View, sums: torch.Tensor, *, cin: int,
+                          cout: int, k: int, z: View, stats: torch.Tensor, act_slope: float = 0.1,
+                          residual: Optional[View] = None) -> int:
+    """y = conv(x) (+ residual), linear, stride 1, bf16 -- a data-gradient convolution whose output is the gradient
+    of the activation leaky(bn(z)) -- and, from the same launch, the per-pixel-tile sums (g, g*z) of that BatchNorm's
+    backward (``stats`` = the producer's [5, cout] statistics).  Returns the number of rows written to ``sums``."""
+    _require_cuda(x.buf, "conv2d_fwd_bnbwd_sums")
+    assert x.buf.dtype == torch.bfloat16 and y.buf.dtype == torch.bfloat16 and z.buf.dtype == torch.bfloat16
+    assert sums.dtype == torch.float32 and sums.is_contiguous()
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= 5 * cout
+    rows = conv_bnsums_rows(x, y, cin, cout, k, 1)
+    xv, yv, zv = x.c(), y.c(), z.c()
+    rv = residual.c() if residual is not None else None
+    flat = stats.view(-1)
+    check(lib().yolo_conv2d_fwd_bnbwd_sums(ctypes.byref(xv), _ptr(w_packed), _ptr(bias),
+                                           ctypes.byref(rv) if rv is not None else None, ctypes.byref(yv), x.N, cin, cout,
+                                           k, dtype_code(x.buf.dtype), ctypes.byref(zv), _ptr(flat[3 * cout:]),
+                                           _ptr(flat[4 * cout:]), float(act_slope), _ptr(sums), sums.numel() * 4,
+                                           _stream()), "yolo_conv2d_fwd_bnbwd_sums")
+    return rows
+
+
+def bn_act_bwd_presummed(dy: View, z: View, stats: torch.Tensor, dz: View, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                         sums: torch.Tensor, rows: int, *, slope: float = 0.1) -> None:
+    """bn_act_bwd when the reduction pass came out of the epilogue that wrote ``dy`` (conv2d_fwd_bnbwd_sums)."""
+    _require_cuda(z.buf, "bn_act_bwd_presummed")
+    assert dy.buf.dtype == z.buf.dtype == dz.buf.dtype
+    assert dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32 and sums.dtype == torch.float32
+    assert sums.numel() >= rows * 2 * z.C
+    dyv, zv, dzv = dy.c(), z.c(), dz.c()
+    check(lib().yolo_bn_act_bwd_presummed(ctypes.byref(dyv), ctypes.byref(zv), _ptr(stats), ctypes.byref(dzv), z.N, z.C,
+                                          float(slope), dtype_code(z.buf.dtype), _ptr(dgamma), _ptr(dbeta), _ptr(sums),
+                                          int(rows), _stream()), "yolo_bn_act_bwd_presummed")
 
 
 def bn_train_finalize(sums: torch.Tensor, rows: int, count: int, gamma: torch.Tensor, beta: torch.Tensor,

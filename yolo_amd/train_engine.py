@@ -8,6 +8,8 @@ fpn.py:33-37,66-71,96-100,165-185 with the modules in training mode) is laid out
                                  yolo_bn_train_stats(z) (+ running-stat update)
                                  yolo_bn_act_fwd(z) (+ residual)         ->  y      [heads: conv + bias only]
   backward, in reverse order:    yolo_bn_act_bwd(dy, z)                  ->  dz, dgamma, dbeta
+                                 (its reduction pass comes out of the epilogue of the launch that wrote dy where
+                                 that is the layer behind it: yolo_conv2d_fwd_bnbwd_sums + yolo_bn_act_bwd_presummed)
                                  yolo_conv2d_wgrad(x, dz)                ->  dW
                                  yolo_conv2d_fwd(dz [dilated for stride 2], W^T rot180) (+ other consumers'
                                  gradient as the fused residual term)    ->  dx
@@ -67,6 +69,8 @@ class TLayer:
     dbeta: Optional[torch.Tensor] = None
     dbias: Optional[torch.Tensor] = None
     arena_end: int = 0                # end of this layer's gradients inside the plan's arena
+    sums_for: Optional["TLayer"] = None   # this layer's data-gradient launch also reduces that layer's BatchNorm backward
+    presummed_rows: int = 0           # rows of such sums waiting in the plan's bn_sums buffer (set during backward)
 
 
 @dataclass
@@ -120,6 +124,7 @@ class TrainEngine:
         self.bucket_bytes = 64 << 20
         self.process_group = None
         self.fuse_bn_sums = os.environ.get("YOLO_FUSE_BN_SUMS", "1") != "0"
+        self.fuse_bn_bwd_sums = os.environ.get("YOLO_FUSE_BN_BWD_SUMS", "1") != "0"
         self.param_arena: Optional[torch.Tensor] = None
         self.grad_arena: Optional[torch.Tensor] = None
         self._adopted: List[Tuple[torch.nn.Parameter, torch.Tensor, torch.Tensor]] = []  # (param, data view, grad view)
@@ -362,6 +367,24 @@ class TrainEngine:
             elif kx in written:
                 L.dx_accumulate = True
             written.add(kx)
+        # The reduction pass of a BatchNorm's backward (two reads of the activation-sized dy and z) comes out of the
+        # epilogue of the data-gradient launch that writes dy, when that launch is the last one to write it: the
+        # consumer directly behind the producer in the plan, reading exactly the producer's output (not a slice of a
+        # concat buffer, not through the upsample), stride 1, bf16.  The sums wait in bn_sums for the very next layer
+        # of the backward pass.
+        if self.fuse_bn_bwd_sums and dt == torch.bfloat16:
+            writers: Dict[int, List[int]] = {}
+            for i, L in enumerate(P.layers):
+                if not L.frozen and L.dx is not None:
+                    writers.setdefault(id(L.dx.buf), []).append(i)
+            for i, L in enumerate(P.layers):
+                if i == 0 or L.frozen or L.dx is None:
+                    continue
+                Q, c = P.layers[i - 1], L.conv
+                if (c.stride == 1 and c.in_channels > 32 and c.in_channels % 8 == 0 and not Q.frozen and Q.z is not None
+                        and Q.up_dst is None and Q.y.buf is L.x.buf and Q.y.ch_offset == L.x.ch_offset
+                        and Q.y.C == L.x.C == L.x.buf.shape[3] and min(writers[id(L.dx.buf)]) == i):
+                    L.sums_for = Q
         # every parameter gradient is a view of one flat arena, in the order backward produces them, so that
         # data-parallel training can all-reduce finished ranges while backward continues (utils/dist.py); the arena
         # belongs to the engine (all plans share it) and the parameters themselves live in its twin
@@ -384,9 +407,12 @@ class TrainEngine:
             L.arena_end = end
         n_bn = max(ops.bn_workspace_bytes(N, L.y.H, L.y.W, L.conv.out_channels) for L in P.layers if L.z is not None)
         P.bn_ws = torch.empty(n_bn, dtype=torch.uint8, device=dev)
-        n_sums = max([ops.conv_bnsums_rows(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels,
-                                           L.conv.kernel_size, dt) * 2 * L.conv.out_channels
+        n_sums = max([ops.conv_bnsums_rows(L.x, L.z, L.conv.in_channels, L.conv.out_channels, L.conv.kernel_size,
+                                           L.conv.stride) * 2 * L.conv.out_channels
                       for L in P.layers if self._sums_in_epilogue(L)], default=0)
+        n_sums = max([n_sums] + [ops.conv_bnsums_rows(L.dz, L.dx, (L.conv.out_channels + 63) // 64 * 64,
+                                                      L.conv.in_channels, L.conv.kernel_size) * 2 * L.conv.in_channels
+                                 for L in P.layers if L.sums_for is not None])
         P.bn_sums = torch.empty(max(n_sums, 1), device=dev)
         n_wg = max(ops.stem_wgrad_workspace_bytes() if L.stem else
                    ops.wgrad_workspace_bytes(N * L.y.H * L.y.W, L.conv.in_channels, L.conv.out_channels, L.conv.kernel_size)
@@ -503,7 +529,12 @@ class TrainEngine:
             else:
                 if L.up_src is not None:
                     ops.sum2x2(L.up_src, L.dy)
-                ops.bn_act_bwd(L.dy, L.z, L.stats, L.dz, L.dgamma, L.dbeta, P.bn_ws, slope=L.slope)
+                if L.presummed_rows:   # the launch that wrote dy (the previous step of this loop) left the reduction
+                    ops.bn_act_bwd_presummed(L.dy, L.z, L.stats, L.dz, L.dgamma, L.dbeta, P.bn_sums, L.presummed_rows,
+                                             slope=L.slope)
+                    L.presummed_rows = 0
+                else:
+                    ops.bn_act_bwd(L.dy, L.z, L.stats, L.dz, L.dgamma, L.dbeta, P.bn_ws, slope=L.slope)
             dz = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, (c.out_channels + 7) // 8 * 8, 0)
             # The weight gradient only feeds the optimizer: it runs on a stream of its own, next to the data gradient
             # and the memory-bound BatchNorm backward of the following layers (it reads x and dz, which nothing
@@ -526,6 +557,12 @@ class TrainEngine:
             cpad = (c.out_channels + 63) // 64 * 64
             src = View(L.dz.buf, L.dz.H, L.dz.W, L.dz.halo, cpad, 0)
             res = L.dx_add if L.dx_add is not None else (L.dx if L.dx_accumulate else None)
+            if L.sums_for is not None:
+                Q = L.sums_for
+                Q.presummed_rows = ops.conv2d_fwd_bnbwd_sums(src, w, b, L.dx, P.bn_sums, cin=cpad, cout=c.in_channels,
+                                                             k=c.kernel_size, z=Q.z, stats=Q.stats, act_slope=Q.slope,
+                                                             residual=res)
+                continue
             if c.stride == 2 and L.dzd is None:   # bf16: straight from dz, only the taps that reach each output pixel
                 ops.conv3x3s2_dgrad(src, w, b, L.dx, cin=cpad, cout=c.in_channels, residual=res)
                 continue
