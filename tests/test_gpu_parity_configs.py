@@ -226,7 +226,10 @@ def test_chained_bf16_meets_5e_2_on_trained_weights(cuda):
     worst416 = {name: rel(out416[name].float().cpu(), ref416[name]) for name in ("p3", "p4", "p5")}
     print("the same at 416 x 416:", {k: round(v, 4) for k, v in worst416.items()})
     assert max(worst416.values()) < 5e-2, worst416
-    # detections: bf16 HIP path against the fp32 oracle's inference()
+    # detections: bf16 HIP path against the fp32 oracle's inference(), on 16 images -- some 55 reference detections, so
+    # that the 95 % is a rate and not "none of eleven" (a detection whose score moves by more than 0.02 between bf16
+    # and fp32 turns up about once in fifty on a network trained this briefly, whichever way it was trained)
+    imgs = torch.stack([d["image"] for d in data[:16]]).cpu()
     got = [_as_rows(r["instances"]) for r in model([dict(image=i) for i in imgs])]
     with torch.no_grad():
         want = R.inference([i.float() for i in imgs], sd, model.num_classes, cfg_thr, cfg_nms, nms_fn=nms_c.nms,
@@ -237,5 +240,5 @@ def test_chained_bf16_meets_5e_2_on_trained_weights(cuda):
         f, n = matched_fraction(w, g, cfg_thr + 0.02, 0.9, 0.02)
         hit += f * n
         n_ref += n
-    assert n_ref >= 6, n_ref
+    assert n_ref >= 30, n_ref
     assert hit / n_ref >= 0.95, (hit, n_ref)
