@@ -415,7 +415,7 @@ def _cpu_baseline(model, cfg):
                 images_per_sec=rows)
 
 
-def _train_throughput(steps: int = 4, warmup: int = 2, batch: int = 64, rank: int = 0, world: int = 1):
+def _train_throughput(steps: int = 12, warmup: int = 4, batch: int = 64, rank: int = 0, world: int = 1):
     """Secondary metric of the same hot path (training images per second): forward + backward + gradient exchange +
     SGD step of configs/yolov3.yaml at 416x416, bf16, synthetic COCO-shaped targets, ``batch`` images per GPU.  With
     world > 1 this is the data-parallel step of the reference's ``launch(main, num_gpus)`` -> DefaultTrainer -> DDP
