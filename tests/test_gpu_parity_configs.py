@@ -185,8 +185,8 @@ def test_chained_bf16_meets_5e_2_on_trained_weights(cuda):
     set (tools/overfit_check.py: 400 bf16 SGD steps through the HIP training path), then its bf16 inference plan is
     compared with the fp32 oracle on the trained state dict: every stage output and head tensor within 5e-2 max-norm
     (measured 0.3e-2 .. 1.7e-2, the same as the oracle's own bf16 restatement -- against 0.10 .. 0.18 on the randomly
-    initialised network, where each stage doubles a perturbation).  And at detection level, with the review's
-    tolerances: at least 95 % of the fp32 oracle's detections above thr + 0.02 have a bf16 twin of the same class at
+    initialised network, where each stage doubles a perturbation).  And at detection level: at
+    least 95 % of the fp32 oracle's detections above thr + 0.02 have a bf16 twin of the same class at
     IoU > 0.9 with a score within 0.02."""
     import os
     import sys
