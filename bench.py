@@ -311,6 +311,16 @@ def _kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def _postproc_source_sha() -> str:
+    """Identifies the decode / NMS kernel sources the post-processing rows of a PMC record belong to."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("decode.hip", "nms.hip", "common.h"):
+        with open(os.path.join(ROOT, "yolo_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _postproc_in_step(w: "Yolov3Inference", steps: int = 6) -> dict:
     """Decode and NMS + gather timed INSIDE pipelined steps (HIP events on the streams they run on, next to the
     following batch's convolutions), against the HBM roofline on two byte counts: the algorithmic bytes (every head
@@ -345,7 +355,22 @@ def _postproc_in_step(w: "Yolov3Inference", steps: int = 6) -> dict:
                         touched_bytes_lower_bound=int(touched), algorithmic_gbytes_per_s=round(alg / t / 1e3, 1),
                         frac_hbm_algorithmic=round(alg / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
                         frac_hbm_touched=round(touched / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+        kind = "decode" if key.startswith("decode") else key
+        if kind in pmc_bytes:
+            out[key]["pmc_hbm_bytes"] = int(pmc_bytes[kind])
+            out[key]["frac_hbm_pmc"] = round(pmc_bytes[kind] / (t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
 
+    # counter bytes of the same kernels (separate rocprofv3 --pmc passes of this command, tools/pmc_summary.py): what
+    # really left L2 per launch, next to the two analytic counts; replayed only for the sources it was taken on
+    pmc_bytes = {}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            rec = json.load(f)
+        if rec.get("postproc_source_sha") == _postproc_source_sha():
+            for name, row in rec.get("postproc_kernels", {}).items():
+                key = "decode" if name.startswith("decode_") else "nms_gather"
+                pmc_bytes[key] = pmc_bytes.get(key, 0) + row["hbm_bytes_per_launch"]
     side = "its own stream, next to the following batch's convolutions (the default: hidden, but it shares the chip)"
     record("decode", "decode", alg_dec, touched_dec, acc, side if eng.decode_on_side_stream else "main stream")
     record("nms_gather", "nms_gather", alg_nms, alg_nms, acc, side if eng.nms_on_side_stream else "main stream")

@@ -6,7 +6,7 @@ Counter unit: KiB.  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request 
 read bytes = 2 * FETCH_SIZE * 1024 (exact for the conv kernels' LDS-DMA loads); WRITE_SIZE is exact.  Infinity-
 Cache hits are counted, so this is traffic leaving L2: an upper bound on DRAM bytes.  Prints a table; the JSON
 (read by bench.py) holds the figures of the kernel named by --kernel-substring (default: the conv instance with
-the most launches x bytes)."""
+the most launches x bytes) and, under "postproc_kernels", those of the decode / NMS / gather kernels."""
 import csv
 import json
 import re
@@ -66,6 +66,18 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def postproc_source_sha():
+    """Hash of the decode / NMS kernel sources: which sources the post-processing rows of the record belong to."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for name in ("decode.hip", "nms.hip", "common.h"):
+        with open(os.path.join(root, "yolo_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     rows = []
@@ -82,8 +94,12 @@ def main():
         convs = [r for r in rows if r[0].startswith("conv_igemm_kernel<bf16,128")]
         recs = {r[0]: dict(kernel=r[0], hbm_bytes_per_launch=round(r[4]), launches_sampled=r[1],
                            fetch_size_kib_per_launch=round(r[2], 1), write_size_kib_per_launch=round(r[3], 1)) for r in convs}
+        # decode / NMS / gather kernels: counter bytes per launch, for bench.py's post-processing block
+        post = {r[0]: dict(hbm_bytes_per_launch=round(r[4]), launches_sampled=r[1]) for r in rows
+                if r[0].startswith(("decode_", "nms_", "gather_"))}
         with open(sys.argv[3], "w") as f:
-            json.dump(dict(kernels=recs, kernel_source_sha=kernel_source_sha(), source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py; "
+            json.dump(dict(kernels=recs, kernel_source_sha=kernel_source_sha(), postproc_kernels=post,
+                           postproc_source_sha=postproc_source_sha(), source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py; "
                                                 "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"), f, indent=1)
 
 
