@@ -405,21 +405,27 @@ static void launch_wgrad_reduce(const void* ws, float* dw, long long n, int spli
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)ws, dw, n, splits, accumulate);
 }
 
-static int wgrad_target_blocks(int k) {
-    // one round of the 512 resident workgroups for the memory-bound 1x1 layers, two for 3x3 (measured optimum)
+static int wgrad_target_blocks(int k, int tiles) {
+    // One round of the 512 resident workgroups for the memory-bound 1x1 layers, and for the 3x3 layers whose output
+    // tiles fit a round at least twice (every split costs a slab of partial sums to write and to add up: 128->256 at
+    // 52x52 142 -> 126 us, 256->512 at 26x26 129 -> 118 us with half the slabs); two rounds where one would leave
+    // slots empty (512->1024: 288 tiles -- one split per tile fills 56 % of a round, three fill 1.7 rounds: 180 vs 140 us).
+#ifdef YOLO_WGRAD_TWO_ROUNDS
     return k == 1 ? 512 : 1024;
+#else
+    return k == 1 || 2 * tiles <= 512 ? 512 : 1024;
+#endif
 }
 
 // `steps` k-steps of 64 pixels (or positions); at most `max_splits` slabs fit the workspace.  512 workgroups are
 // resident at a time (two per CU): the split count is the largest that keeps the grid within a whole number of
-// such rounds (one for the memory-bound 1x1 layers, whose slabs cost as much as their operands; two for 3x3) --
-// a few workgroups more than that would run as a round of their own.
+// such rounds (wgrad_target_blocks) -- a few workgroups more than that would run as a round of their own.
 static void wgrad_plan(int steps, int Cin, int Cout, int k, long long max_splits, int* n_mt, int* n_nt, int* splits,
                        int* steps_per_split) {
     *n_mt = (Cout + 127) / 128;
     *n_nt = (Cin + 127) / 128;
     const int tiles = *n_mt * *n_nt * k * k;
-    long long s = wgrad_target_blocks(k) / tiles;
+    long long s = wgrad_target_blocks(k, tiles) / tiles;
     if (s > steps / 8) s = steps / 8;     // at least 8 k-steps per workgroup: a partial tile costs 64 KiB of slab
     if (s > max_splits) s = max_splits;
     if (s < 1) s = 1;
