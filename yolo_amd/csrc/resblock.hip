@@ -13,8 +13,8 @@
 //
 // LDS image of t: one 64-byte row per patch pixel, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 3):
 // the ds_read_b128 of 16 consecutive rows (one MFMA operand of a tap) and the producer's ds_write_b128 are
-// bank-conflict free.  Two thirds of the 64 x 288 conv2 weights stay in registers for the whole launch, the rest
-// in LDS in MFMA-fragment order.
+// bank-conflict free.  A wave owns 32 output channels of four rows of the tile; its share of the conv2 weights
+// (32 x 288) stays in registers for the whole launch.
 #include "common.h"
 
 namespace yolo {
@@ -24,7 +24,6 @@ constexpr int RB_PH = RB_TH + 2, RB_PW = RB_TW + 2;
 constexpr int RB_PIX = RB_PH * RB_PW;         // 180 patch pixels
 constexpr int RB_NT = (RB_PIX + 15) / 16;     // 12 producer n-tiles
 constexpr int RB_PER = RB_NT / 4;             // per wave
-constexpr int RB_TREG = 6;                    // conv2 taps whose weights live in registers
 static_assert(RB_NT % 4 == 0, "producer tiles split evenly over the 4 waves");
 
 struct ResBlockParams {
@@ -41,10 +40,12 @@ struct ResBlockParams {
     float slope;
 };
 
-__global__ void __launch_bounds__(256, 2) resblock_c64_kernel(const ResBlockParams p) {
+#ifndef RB_WGS
+#define RB_WGS 2
+#endif
+__global__ void __launch_bounds__(256, RB_WGS) resblock_c64_kernel(const ResBlockParams p) {
     __shared__ __attribute__((aligned(16))) char patch[RB_NT * 16 * 64];
     __shared__ __attribute__((aligned(16))) bf16x8 w1frag_s[4 * 64];
-    __shared__ __attribute__((aligned(16))) bf16x8 w2frag_s[(9 - RB_TREG) * 4 * 64];
     __shared__ __attribute__((aligned(16))) float bias_s[32 + 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,25 +64,22 @@ __global__ void __launch_bounds__(256, 2) resblock_c64_kernel(const ResBlockPara
     if (tid < 32) bias_s[tid] = p.b1[tid];
     if (tid >= 64 && tid < 128) bias_s[32 + tid - 64] = p.b2[tid - 64];
 
-    // conv2 weights: m-tile i = 2*pr + f, same row permutation inside each 32-channel pair pr.  Taps 0..5 stay
-    // in registers for the whole launch, taps 6..8 in LDS in fragment order (register budget: 2 waves per SIMD)
-    bf16x8 dfrag[4][RB_TREG];
+    // conv2: wave = 32 channels (wc) x 4 output rows (4 * wp ..) of 16 pixels.  Its weights -- two m-tiles of the same
+    // row permutation as conv1's, all nine taps -- stay in registers for the whole launch (18 fragments; a 64-channel
+    // wave would need 36 and had to keep a third of them in LDS).
+    const int wc = wave & 1, wp = wave >> 1;
+    bf16x8 dfrag[2][9];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = 32 * (i >> 1) + 8 * (l15 >> 2) + 4 * (i & 1) + (l15 & 3);
+    for (int i = 0; i < 2; ++i) {
+        const int ch = 32 * wc + 8 * (l15 >> 2) + 4 * i + (l15 & 3);
 #pragma unroll
-        for (int t = 0; t < RB_TREG; ++t) dfrag[i][t] = *(const bf16x8*)(p.w2 + (size_t)ch * 320 + t * 32 + q * 8);
-        if (wave == 1) {
-#pragma unroll
-            for (int t = RB_TREG; t < 9; ++t)
-                w2frag_s[((t - RB_TREG) * 4 + i) * 64 + lane] = *(const bf16x8*)(p.w2 + (size_t)ch * 320 + t * 32 + q * 8);
-        }
+        for (int t = 0; t < 9; ++t) dfrag[i][t] = *(const bf16x8*)(p.w2 + (size_t)ch * 320 + t * 32 + q * 8);
     }
     // pin the fragments in registers (after all loads are issued): otherwise the compiler re-loads them per tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < RB_TREG; ++t) asm volatile("" : "+v"(dfrag[i][t]));
+        for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(dfrag[i][t]));
 
     // tile-independent patch coordinates of this lane's producer pixels
     int ppy[RB_PER], ppx[RB_PER];
@@ -155,68 +153,57 @@ __global__ void __launch_bounds__(256, 2) resblock_c64_kernel(const ResBlockPara
         //      waits only for the former
         const char* xn = p.x + p.x_origin + (long long)n * p.x_img_stride;
         const int ox = ox0 + l15;
-        u32x4 res[2][2];
+        u32x4 res[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oy = oy0 + 2 * wave + j;
+        for (int j = 0; j < 4; ++j) {
+            const int oy = oy0 + 4 * wp + j;
             const bool in = oy < p.H && ox < p.W;
             const int off = in ? oy * p.x_row_stride + ox * p.x_pix_stride : 0;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) res[j][pr] = *(const u32x4*)(xn + off + 64 * pr + q * 16);
+            res[j] = *(const u32x4*)(xn + off + 64 * wc + q * 16);
         }
         if (tile + (int)gridDim.x < p.tiles) prefetch(tile + gridDim.x);
 
-        // ---- conv2 (3x3, 32 -> 64): wave = 64 channels x 32 pixels (output rows 2*wave, 2*wave+1 of the tile)
-        f32x4 acc[4][2];
+        // ---- conv2 (3x3, 32 -> 64): wave = 32 channels x 64 pixels (output rows 4*wp .. 4*wp + 3 of the tile)
+        f32x4 acc[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 bi = *(const f32x4*)&bias_s[32 + 32 * (i >> 1) + 8 * q + 4 * (i & 1)];
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 bi = *(const f32x4*)&bias_s[32 + 32 * wc + 8 * q + 4 * i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = bi;
+            for (int j = 0; j < 4; ++j) acc[i][j] = bi;
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ky = t / 3, kx = t - 3 * ky;
-            bf16x8 b[2];
+            bf16x8 b[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = (2 * wave + j + ky) * RB_PW + l15 + kx;
+            for (int j = 0; j < 4; ++j) {
+                const int r = (4 * wp + j + ky) * RB_PW + l15 + kx;
                 b[j] = *(const bf16x8*)(patch + r * 64 + ((q ^ ((r >> 1) & 3)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf16x8 a;
-                if (t < RB_TREG)
-                    a = dfrag[i][t < RB_TREG ? t : 0];
-                else
-                    a = w2frag_s[((t - RB_TREG) * 4 + i) * 64 + lane];
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfrag[i][t], b[j], acc[i][j], 0, 0, 0);
         }
 
-        // ---- epilogue: LeakyReLU, + residual, 8 consecutive channels (16 bytes) per lane and channel pair
+        // ---- epilogue: LeakyReLU, + residual, 8 consecutive channels (16 bytes) per lane
         char* yn = p.y + p.y_origin + (long long)n * p.y_img_stride;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oy = oy0 + 2 * wave + j;
+        for (int j = 0; j < 4; ++j) {
+            const int oy = oy0 + 4 * wp + j;
             if (oy < p.H && ox < p.W) {
-                char* o = yn + (oy * p.y_row_stride + ox * p.y_pix_stride + q * 16);
+                f32x4 lo = leaky4(acc[0][j], p.slope), hi = leaky4(acc[1][j], p.slope);
+                const u32x4 r = res[j];
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    f32x4 lo = leaky4(acc[2 * pr][j], p.slope), hi = leaky4(acc[2 * pr + 1][j], p.slope);
-                    const u32x4 r = res[j][pr];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        lo[2 * e] += __uint_as_float(r[e] << 16);
-                        lo[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
-                        hi[2 * e] += __uint_as_float(r[2 + e] << 16);
-                        hi[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
-                    }
-                    const u32x4 pk = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                                      pack_bf16x2(hi[2], hi[3])};
-                    *(u32x4*)(o + 64 * pr) = pk;
+                for (int e = 0; e < 2; ++e) {
+                    lo[2 * e] += __uint_as_float(r[e] << 16);
+                    lo[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                    hi[2 * e] += __uint_as_float(r[2 + e] << 16);
+                    hi[2 * e + 1] += __uint_as_float(r[2 + e] & 0xffff0000u);
                 }
+                const u32x4 pk = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                  pack_bf16x2(hi[2], hi[3])};
+                *(u32x4*)(yn + (oy * p.y_row_stride + ox * p.y_pix_stride + 64 * wc + q * 16)) = pk;
             }
         }
         __syncthreads();  // all conv2 reads of the patch are done before the next tile's conv1 writes it

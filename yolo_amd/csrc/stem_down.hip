@@ -26,6 +26,9 @@ constexpr int SD_NT = (SD_ROWS + 15) / 16;       // 37 stem n-tiles of 16 pixels
 constexpr int SD_IH = SD_PH + 2, SD_IW = SD_PW + 3;  // 19 x 36 image pixels (the k chunk spans 4 pixels)
 constexpr int SD_IPIX = SD_IH * SD_IW;           // 684
 constexpr int SD_PRE = (SD_IPIX + 255) / 256;    // image pixels per thread
+#ifndef SD_WGS
+#define SD_WGS 2                                 // workgroups per CU the register budget is set for (3 would need <= 168 registers: it spills)
+#endif
 
 struct StemDownParams {
     const void* img;
@@ -46,7 +49,7 @@ struct StemDownParams {
 };
 
 template <typename IMG>
-__global__ void __launch_bounds__(256, 2) stem_down_kernel(const StemDownParams p) {
+__global__ void __launch_bounds__(256, SD_WGS) stem_down_kernel(const StemDownParams p) {
     // RGB0 bf16 pixels; 3 slack rows stay zero (the zero-weight k chunks and the unused odd slot read them)
     __shared__ __attribute__((aligned(16))) unsigned long long img_t[SD_IPIX + 3 * SD_IW];
     __shared__ unsigned short lut[3 * 256];  // u8 images: bf16((v - mean[c]) / std[c]) for every byte value
@@ -85,17 +88,20 @@ __global__ void __launch_bounds__(256, 2) stem_down_kernel(const StemDownParams 
     if (tid < 32) bias_s[tid] = p.b_stem[tid];
     if (tid >= 64 && tid < 128) bias_s[32 + tid - 64] = p.b_down[tid - 64];
 
-    // down-conv weights: m-tile i = 2*pr + f, same row permutation inside each 32-channel pair pr
-    bf16x8 dfrag[4][9];
+    // down conv: wave = 32 channels (wc) x 4 output rows (4 * wp ..) of 16 pixels.  Its weights, two m-tiles of the
+    // same row permutation as the stem's, stay in registers for the whole launch: 18 fragments -- half of what a
+    // 64-channel wave would hold, which is what lets three workgroups share a CU.
+    const int wc = wave & 1, wp = wave >> 1;
+    bf16x8 dfrag[2][9];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = 32 * (i >> 1) + 8 * (l15 >> 2) + 4 * (i & 1) + (l15 & 3);
+    for (int i = 0; i < 2; ++i) {
+        const int ch = 32 * wc + 8 * (l15 >> 2) + 4 * i + (l15 & 3);
 #pragma unroll
         for (int t = 0; t < 9; ++t) dfrag[i][t] = *(const bf16x8*)(p.w_down + (size_t)ch * 320 + t * 32 + q * 8);
     }
-    // pin the fragments in registers (after all loads are issued): otherwise the compiler re-loads all 36 per tile
+    // pin the fragments in registers (after all loads are issued): otherwise the compiler re-loads them per tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(dfrag[i][t]));
     const int plane = p.Hs * p.Ws;
@@ -205,45 +211,41 @@ __global__ void __launch_bounds__(256, 2) stem_down_kernel(const StemDownParams 
         }
         __syncthreads();
 
-        // ---- down conv: wave = 64 channels x 32 pixels (output rows 2*wave, 2*wave+1 of the tile)
-        f32x4 acc[4][2];
+        // ---- down conv: wave = 32 channels x 64 pixels (output rows 4*wp .. 4*wp + 3 of the tile)
+        f32x4 acc[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 bi = *(const f32x4*)&bias_s[32 + 32 * (i >> 1) + 8 * q + 4 * (i & 1)];
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 bi = *(const f32x4*)&bias_s[32 + 32 * wc + 8 * q + 4 * i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = bi;
+            for (int j = 0; j < 4; ++j) acc[i][j] = bi;
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ky = t / 3, kx = t - 3 * ky;
-            bf16x8 b[2];
+            bf16x8 b[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = ((2 * (2 * wave + j) + ky) * 2 + (kx & 1)) * SD_HALF + l15 + (kx >> 1);
+            for (int j = 0; j < 4; ++j) {
+                const int r = ((2 * (4 * wp + j) + ky) * 2 + (kx & 1)) * SD_HALF + l15 + (kx >> 1);
                 b[j] = *(const bf16x8*)(patch + r * 64 + ((q ^ ((r >> 1) & 3)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfrag[i][t], b[j], acc[i][j], 0, 0, 0);
         }
 
-        // ---- epilogue: LeakyReLU, 8 consecutive channels (16 bytes) per lane and channel pair
+        // ---- epilogue: LeakyReLU, 8 consecutive channels (16 bytes) per lane
         const int ox = ox0 + l15;
         char* ybase = p.y + p.y_origin + (long long)n * p.y_img_stride;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oy = oy0 + 2 * wave + j;
+        for (int j = 0; j < 4; ++j) {
+            const int oy = oy0 + 4 * wp + j;
             if (oy < p.Ho && ox < p.Wo) {
-                char* o = ybase + (oy * p.y_row_stride + ox * p.y_pix_stride + q * 16);
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const f32x4 lo = leaky4(acc[2 * pr][j], p.slope), hi = leaky4(acc[2 * pr + 1][j], p.slope);
-                    const u32x4 pk = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
-                                      pack_bf16x2(hi[2], hi[3])};
-                    *(u32x4*)(o + 64 * pr) = pk;
-                }
+                const f32x4 lo = leaky4(acc[0][j], p.slope), hi = leaky4(acc[1][j], p.slope);
+                const u32x4 pk = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]),
+                                  pack_bf16x2(hi[2], hi[3])};
+                *(u32x4*)(ybase + (oy * p.y_row_stride + ox * p.y_pix_stride + 64 * wc + q * 16)) = pk;
             }
         }
         // the next iteration's image-patch barrier orders this tile's patch reads before the next writes
