@@ -180,7 +180,10 @@ __global__ void __launch_bounds__(256, SD_WGS) stem_down_kernel(const StemDownPa
         // stem pixels outside the stem output are the down conv's zero padding (0, not stem(0)): only tiles on
         // the border have any
         const bool border = oy0 == 0 || ox0 == 0 || 2 * (oy0 + SD_TH) >= p.Hst || 2 * (ox0 + SD_TW) >= p.Wst;
-        for (int t = wave; t < SD_NT; t += 4) {
+#pragma unroll
+        for (int it = 0; it < (SD_NT + 3) / 4; ++it) {
+            const int t = wave + 4 * it;
+            if (t >= SD_NT) break;
             const int r = 16 * t + l15;
             const int py = (r * 1928) >> 16;  // r / 34 for r < 592
             const int rem = r - py * (2 * SD_HALF);
